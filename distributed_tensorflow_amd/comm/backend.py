@@ -1,0 +1,162 @@
+"""Process-group layer: one process per GPU on ``torch.distributed``.
+
+On a GPU node the backend is ``"nccl"``, which on ROCm is RCCL over xGMI; in the
+CPU plumbing mode it is ``"gloo"`` over loopback, the direct analogue of the
+reference's habit of running every role as a local process on 127.0.0.1
+(reference initializer.py:134-145,164-173; centralized/server.py:160-163).
+
+:class:`Comm` is a thin, explicit wrapper: every collective the strategies use
+goes through it, world-size-1 runs short-circuit without a process group, and
+every blocking call is bounded by the group timeout so a dead peer surfaces as
+an error instead of the reference's indefinite ``barrier.wait()``
+(centralized/server.py:95).
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from typing import Sequence
+
+import torch
+import torch.distributed as dist
+
+
+class Comm:
+    def __init__(self, rank: int = 0, world: int = 1, device: torch.device | str = "cpu", group=None):
+        self.rank, self.world = rank, world
+        self.device = torch.device(device)
+        self.group = group
+
+    # ------------------------------------------------------------------ setup
+    @classmethod
+    def init(cls, rank: int, world: int, device: torch.device | str, master_addr: str = "127.0.0.1",
+             master_port: int = 29500, timeout_s: float = 300.0, backend: str | None = None) -> "Comm":
+        device = torch.device(device)
+        if world == 1:
+            return cls(0, 1, device)
+        if backend is None:
+            backend = "nccl" if device.type == "cuda" else "gloo"
+        if not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            kw = {}
+            if backend == "nccl":
+                kw["device_id"] = device
+            dist.init_process_group(backend, init_method=f"tcp://{master_addr}:{master_port}", rank=rank,
+                                    world_size=world, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+        return cls(rank, world, device)
+
+    @classmethod
+    def from_env(cls, device: torch.device | str, timeout_s: float = 300.0) -> "Comm":
+        """Rendezvous from the RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT that ``torchrun`` exports."""
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        return cls.init(rank, world, device, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                        int(os.environ.get("MASTER_PORT", "29500")), timeout_s)
+
+    def subgroup(self, ranks: Sequence[int]) -> "Comm":
+        """A communicator over ``ranks`` (collective call on the parent group)."""
+        g = dist.new_group(list(ranks))
+        r = list(ranks).index(self.rank) if self.rank in ranks else -1
+        c = Comm(r, len(ranks), self.device, g)
+        c._global_ranks = list(ranks)
+        return c
+
+    def _g(self, r: int) -> int:
+        """Group rank -> global rank (P2P calls take global ranks)."""
+        gr = getattr(self, "_global_ranks", None)
+        return gr[r] if gr is not None else r
+
+    def shutdown(self) -> None:
+        if self.world > 1 and self.group is None and dist.is_initialized():
+            dist.destroy_process_group()
+
+    # ------------------------------------------------------------ collectives
+    def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM, async_op: bool = False):
+        if self.world == 1:
+            return None
+        return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
+
+    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        """out (1/world of inp) = sum over ranks of the matching slice of inp."""
+        if self.world == 1:
+            if out.data_ptr() != inp.data_ptr():
+                out.copy_(inp)
+            return None
+        if self.device.type == "cpu":
+            # gloo has no reduce_scatter: reduce the whole buffer, keep the local slice
+            w = dist.all_reduce(inp, group=self.group, async_op=False)
+            n = out.numel()
+            if out.data_ptr() != inp[self.rank * n:].data_ptr():
+                out.copy_(inp[self.rank * n:(self.rank + 1) * n])
+            return w
+        return dist.reduce_scatter_tensor(out, inp, group=self.group, async_op=async_op)
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        if self.world == 1:
+            if out.data_ptr() != inp.data_ptr():
+                out.copy_(inp)
+            return None
+        if self.device.type == "cpu":
+            n = inp.numel()
+            chunks = [out[i * n:(i + 1) * n] for i in range(self.world)]
+            src = inp.clone() if inp.data_ptr() == chunks[self.rank].data_ptr() else inp
+            return dist.all_gather(chunks, src, group=self.group, async_op=async_op)
+        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        if self.world == 1:
+            out.copy_(inp)
+            return None
+        if self.device.type == "cpu":
+            n = inp.numel() // self.world
+            ops = []
+            for r in range(self.world):
+                if r == self.rank:
+                    out[r * n:(r + 1) * n].copy_(inp[r * n:(r + 1) * n])
+                    continue
+                ops.append(dist.P2POp(dist.isend, inp[r * n:(r + 1) * n], self._g(r), group=self.group))
+                ops.append(dist.P2POp(dist.irecv, out[r * n:(r + 1) * n], self._g(r), group=self.group))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            return None
+        return dist.all_to_all_single(out, inp, group=self.group, async_op=async_op)
+
+    def broadcast(self, t: torch.Tensor, src: int = 0, async_op: bool = False):
+        if self.world == 1:
+            return None
+        return dist.broadcast(t, src=self._g(src), group=self.group, async_op=async_op)
+
+    def reduce(self, t: torch.Tensor, dst: int = 0, async_op: bool = False):
+        if self.world == 1:
+            return None
+        return dist.reduce(t, dst=self._g(dst), group=self.group, async_op=async_op)
+
+    def barrier(self) -> None:
+        if self.world > 1:
+            if self.device.type == "cuda":
+                dist.barrier(group=self.group, device_ids=[self.device.index or 0])
+            else:
+                dist.barrier(group=self.group)
+
+    # -------------------------------------------------------------------- p2p
+    def send(self, t: torch.Tensor, dst: int) -> None:
+        dist.send(t, self._g(dst), group=self.group)
+
+    def recv(self, t: torch.Tensor, src: int) -> None:
+        dist.recv(t, self._g(src), group=self.group)
+
+    def exchange(self, sends: Sequence[tuple[torch.Tensor, int]], recvs: Sequence[tuple[torch.Tensor, int]]):
+        """Grouped point-to-point: post every send and receive as ONE batch (one RCCL group
+        call, so transfers to different peers run concurrently over their own xGMI links)."""
+        if not sends and not recvs:
+            return []
+        ops = [dist.P2POp(dist.isend, t, self._g(d), group=self.group) for t, d in sends]
+        ops += [dist.P2POp(dist.irecv, t, self._g(s), group=self.group) for t, s in recvs]
+        return dist.batch_isend_irecv(ops)
+
+    def all_reduce_scalar(self, v: float, op=dist.ReduceOp.SUM) -> float:
+        if self.world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64 if self.device.type == "cpu" else torch.float32, device=self.device)
+        dist.all_reduce(t, op=op, group=self.group)
+        return float(t)

@@ -1,0 +1,115 @@
+"""In-tree build of the native libraries.
+
+Two shared objects are produced under ``distributed_tensorflow_amd/lib``:
+
+``libdtf_kernels.so``
+    every ``csrc/kernels/*.hip`` file, compiled by ``hipcc`` for gfx950 only
+    (device code) and exported through a C ABI that takes raw device
+    pointers and a ``hipStream_t``.
+
+``libdtf_runtime.so``
+    the host runtime in ``csrc/runtime/*.cpp`` (framed TCP transport,
+    parameter-server core, data loader, RCCL communicator, IPC peer memory),
+    compiled by ``hipcc`` as host code and linked against ``libamdhip64`` and
+    ``librccl``.
+
+Objects are rebuilt only when their source (or a header) is newer, so calling
+:func:`build_all` repeatedly is cheap. Run ``python -m
+distributed_tensorflow_amd.csrc.build`` to build from the shell.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+PKG = CSRC.parent
+LIB_DIR = PKG / "lib"
+OBJ_DIR = CSRC / "build"
+ARCH = "gfx950"
+ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or str(ROCM / "bin" / "hipcc")
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found; a ROCm toolchain is required to build the native libraries")
+    return exe
+
+
+def _newer(src: Path, deps: list[Path], out: Path) -> bool:
+    if not out.exists():
+        return True
+    t = out.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in [src, *deps])
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+    if r.stderr.strip() and os.environ.get("DTF_BUILD_VERBOSE"):
+        sys.stderr.write(r.stderr)
+
+
+def _compile_objects(srcs: list[Path], headers: list[Path], flags: list[str], tag: str, jobs: int) -> list[Path]:
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    hipcc = _hipcc()
+    objs, todo = [], []
+    for s in srcs:
+        o = OBJ_DIR / f"{tag}_{s.stem}.o"
+        objs.append(o)
+        if _newer(s, headers + [Path(__file__)], o):
+            todo.append([hipcc, *flags, "-c", str(s), "-o", str(o)])
+    if todo:
+        with cf.ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+            list(ex.map(_run, todo))
+    return objs
+
+
+def build_kernels(jobs: int = 8, force: bool = False) -> Path:
+    kdir = CSRC / "kernels"
+    srcs = sorted(kdir.glob("*.hip"))
+    headers = sorted(kdir.glob("*.h"))
+    out = LIB_DIR / "libdtf_kernels.so"
+    if force and out.exists():
+        out.unlink()
+    flags = ["-x", "hip", f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
+             "-ffast-math", "-fno-finite-math-only", "-munsafe-fp-atomics", f"-I{kdir}"]
+    objs = _compile_objects(srcs, headers, flags, "k", jobs)
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    if force or any(_newer(o, [], out) for o in objs):
+        _run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(out), *map(str, objs)])
+    return out
+
+
+def build_runtime(jobs: int = 8, force: bool = False) -> Path:
+    rdir = CSRC / "runtime"
+    srcs = sorted(rdir.glob("*.cpp"))
+    headers = sorted(rdir.glob("*.h"))
+    out = LIB_DIR / "libdtf_runtime.so"
+    if force and out.exists():
+        out.unlink()
+    flags = ["-O2", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-pthread", "-D__HIP_PLATFORM_AMD__",
+             f"-I{rdir}", f"-I{ROCM / 'include'}"]
+    extra = os.environ.get("DTF_RUNTIME_CXXFLAGS", "").split()
+    objs = _compile_objects(srcs, headers, flags + extra, "r", jobs)
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    if force or any(_newer(o, [], out) for o in objs):
+        _run([_hipcc(), "-shared", "-fPIC", "-pthread", "-o", str(out), *map(str, objs), *extra,
+              f"-L{ROCM / 'lib'}", "-lamdhip64", "-lrccl", f"-Wl,-rpath,{ROCM / 'lib'}"])
+    return out
+
+
+def build_all(jobs: int = 8, force: bool = False) -> dict[str, Path]:
+    return {"kernels": build_kernels(jobs, force), "runtime": build_runtime(jobs, force)}
+
+
+if __name__ == "__main__":
+    res = build_all(force="--force" in sys.argv)
+    for k, v in res.items():
+        print(f"{k}: {v} ({v.stat().st_size} bytes)")

@@ -1,0 +1,80 @@
+"""ctypes loader for the in-tree native libraries.
+
+The HIP kernels are exported through a C ABI (raw device pointers plus a
+``hipStream_t``), so the Python side needs no compiled binding layer: a call is
+``lib.fn(tensor.data_ptr(), ..., stream)``. ctypes releases the GIL for the
+duration of the call, which the parameter-server threads rely on.
+
+Tensors on a GPU never fall back to an eager implementation: if the kernel
+library is missing, :func:`kernels` raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import torch
+
+_LIB_DIR = Path(__file__).resolve().parent.parent / "lib"
+_kernels = None
+_runtime = None
+
+F32, BF16 = 0, 1
+_DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def _load(name: str) -> ctypes.CDLL:
+    path = _LIB_DIR / name
+    if not path.exists():
+        if os.environ.get("DTF_AUTO_BUILD", "1") == "1":
+            try:
+                from ..csrc import build
+
+                (build.build_kernels if "kernels" in name else build.build_runtime)()
+            except Exception as e:  # pragma: no cover - depends on toolchain
+                raise NativeLibraryMissing(f"{path} is missing and could not be built: {e}") from e
+        if not path.exists():
+            raise NativeLibraryMissing(
+                f"{path} is missing; run `python -m distributed_tensorflow_amd.csrc.build`")
+    return ctypes.CDLL(str(path), mode=ctypes.RTLD_GLOBAL)
+
+
+def kernels() -> ctypes.CDLL:
+    """The HIP kernel library (``libdtf_kernels.so``)."""
+    global _kernels
+    if _kernels is None:
+        _kernels = _load("libdtf_kernels.so")
+    return _kernels
+
+
+def runtime() -> ctypes.CDLL:
+    """The host runtime library (``libdtf_runtime.so``)."""
+    global _runtime
+    if _runtime is None:
+        _runtime = _load("libdtf_runtime.so")
+    return _runtime
+
+
+def dtype_code(t: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODE[t]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t}; the kernels take float32 and bfloat16") from None
+
+
+def stream_ptr(device=None) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t: torch.Tensor | None) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what} failed with HIP/launch status {code}")

@@ -1,0 +1,150 @@
+"""Python front end of the bf16 MFMA GEMM (``csrc/kernels/gemm.hip``).
+
+Three entry points, one per product of a dense / 1x1-convolution layer:
+
+* :func:`gemm_nt` -- ``C[M,N] = act(A[M,K] @ B[N,K]^T + bias)`` (forward);
+* :func:`gemm_nn` -- ``C[M,N] = A[M,K] @ B[K,N]`` (data gradient);
+* :func:`gemm_tn` -- ``C[M,N] = A[K,M]^T @ B[K,N]`` (weight gradient; the contraction
+  runs over the batch, so it is split-K'd to fill the 256 CUs).
+
+The kernel needs 16-byte aligned rows (leading dimensions and the contiguous
+extents multiples of 8 bf16); :func:`supported` reports whether a pair of
+operands qualifies. Callers route everything else to the library GEMM.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+_ACT = {None: 0, "relu": 1, "gelu": 2}
+NT, NN, TN = 0, 1, 2
+_N_CU = 256
+
+
+def _ok2d(t: torch.Tensor) -> bool:
+    return (t.dim() == 2 and t.dtype == torch.bfloat16 and t.stride(1) == 1 and t.stride(0) % 8 == 0
+            and t.data_ptr() % 16 == 0 and t.shape[1] % 8 == 0)
+
+
+def supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """True when ``x[..., K] @ w[N, K]^T`` and both of its gradients can run on the MFMA kernel."""
+    K = x.shape[-1]
+    N = w.shape[0]
+    return (x.is_cuda and K % 8 == 0 and N % 8 == 0 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and w.is_contiguous() and x.numel() > 0)
+
+
+_workspaces: dict[tuple, torch.Tensor] = {}
+
+
+def _workspace(device, numel: int) -> torch.Tensor:
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < numel:
+        ws = torch.empty(max(numel, 1 << 22), dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _pick_splits(M: int, N: int, K: int) -> int:
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= _N_CU or K <= 512:
+        return 1
+    want = max(1, (2 * _N_CU) // tiles)
+    return max(1, min(want, K // 256, 64))
+
+
+def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, splits, out=None):
+    dev = A.device
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=dev)
+    if N % 8 or out.stride(1) != 1 or out.data_ptr() % 16:
+        raise ValueError("gemm output needs N % 8 == 0 and a 16-byte aligned row-major buffer")
+    if splits is None:
+        splits = _pick_splits(M, N, K)
+    ws = _workspace(dev, splits * M * N) if splits > 1 else None
+    bias_dtype = 0
+    if bias is not None:
+        if bias.numel() != N or not bias.is_contiguous():
+            raise ValueError("bias must be a contiguous [N] vector")
+        bias_dtype = _lib.dtype_code(bias.dtype)
+    rc = _lib.kernels().dtf_gemm_bf16(layout, _lib.ptr(A), _lib.ptr(B), _lib.ptr(out), _lib.ptr(bias), M, N, K,
+                                      ctypes.c_longlong(lda), ctypes.c_longlong(ldb),
+                                      ctypes.c_longlong(out.stride(0)), bias_dtype, _ACT[activation],
+                                      1 if out.dtype == torch.float32 else 0, splits, _lib.ptr(ws),
+                                      _lib.stream_ptr(dev))
+    _lib.check(rc, "gemm_bf16")
+    return out
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, activation=None, out_dtype=torch.bfloat16, splits=None,
+            out=None) -> torch.Tensor:
+    """``act(a[M,K] @ b[N,K]^T + bias)``."""
+    if not (_ok2d(a) and _ok2d(b)) or a.shape[1] != b.shape[1]:
+        raise ValueError("gemm_nt: operands must be 16-byte aligned bf16 [M,K] and [N,K]")
+    return _launch(NT, a, b, a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0), bias, activation,
+                   out_dtype, splits, out)
+
+
+def gemm_nn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=None, out=None) -> torch.Tensor:
+    """``a[M,K] @ b[K,N]``."""
+    if not (_ok2d(a) and _ok2d(b)) or a.shape[1] != b.shape[0]:
+        raise ValueError("gemm_nn: operands must be 16-byte aligned bf16 [M,K] and [K,N]")
+    return _launch(NN, a, b, a.shape[0], b.shape[1], a.shape[1], a.stride(0), b.stride(0), None, None, out_dtype,
+                   splits, out)
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=None, out=None) -> torch.Tensor:
+    """``a[K,M]^T @ b[K,N]``."""
+    if not (_ok2d(a) and _ok2d(b)) or a.shape[0] != b.shape[0]:
+        raise ValueError("gemm_tn: operands must be 16-byte aligned bf16 [K,M] and [K,N]")
+    return _launch(TN, a, b, a.shape[1], b.shape[1], a.shape[0], a.stride(0), b.stride(0), None, None, out_dtype,
+                   splits, out)
+
+
+def _ew(op: int, a: torch.Tensor, b: torch.Tensor | None) -> torch.Tensor:
+    a = a.contiguous()
+    if b is not None:
+        b = b.contiguous()
+    out = torch.empty_like(a)
+    rc = _lib.kernels().dtf_ew_bf16(op, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), ctypes.c_longlong(a.numel()),
+                                    _lib.stream_ptr(a.device))
+    _lib.check(rc, "ew_bf16")
+    return out
+
+
+def relu_bwd(g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """``g * (y > 0)`` from the ReLU OUTPUT."""
+    if g.is_cuda and g.dtype == torch.bfloat16:
+        return _ew(0, g, y)
+    return g * (y > 0).to(g.dtype)
+
+
+def gelu_bwd(g: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
+    """``g * gelu'(pre)`` (erf form) from the PRE-activation."""
+    if g.is_cuda and g.dtype == torch.bfloat16:
+        return _ew(1, g, pre)
+    x = pre.float()
+    cdf = 0.5 * (1 + torch.erf(x * 0.7071067811865476))
+    pdf = torch.exp(-0.5 * x * x) * 0.3989422804014327
+    return (g.float() * (cdf + x * pdf)).to(g.dtype)
+
+
+def gelu_fwd(x: torch.Tensor) -> torch.Tensor:
+    if x.is_cuda and x.dtype == torch.bfloat16:
+        return _ew(2, x, None)
+    return torch.nn.functional.gelu(x)
+
+
+def col_sum(g: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    """Column sums of a row-major [M, N] matrix (the bias gradient)."""
+    if g.is_cuda and g.dtype == torch.bfloat16 and g.shape[1] % 8 == 0 and g.stride(1) == 1 and g.data_ptr() % 16 == 0:
+        out = torch.zeros(g.shape[1], dtype=torch.float32, device=g.device)
+        rc = _lib.kernels().dtf_col_sum_bf16(_lib.ptr(g), _lib.ptr(out), g.shape[0], g.shape[1],
+                                             ctypes.c_longlong(g.stride(0)), _lib.stream_ptr(g.device))
+        _lib.check(rc, "col_sum_bf16")
+        return out.to(dtype)
+    return g.float().sum(0).to(dtype)

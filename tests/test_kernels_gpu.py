@@ -1,0 +1,209 @@
+"""Numerics of every HIP kernel against a plain PyTorch fp32 reference (GPU only)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _lib_loaded():
+    from distributed_tensorflow_amd.ops import _lib
+    _lib.kernels()
+    with open("/proc/self/maps") as f:
+        return "libdtf_kernels.so" in f.read()
+
+
+def test_native_library_is_loaded():
+    assert _lib_loaded()
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 1000, 407050, 1 << 20 | 3])
+@pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_adam_matches_reference(n, gdtype, mode):
+    from distributed_tensorflow_amd.ops import optim as K
+    torch.manual_seed(n + mode)
+    npad = (n + 63) // 64 * 64
+    p = torch.randn(npad, device=DEV); g = torch.randn(npad, device=DEV).to(gdtype)
+    m = torch.zeros(npad, device=DEV); v = torch.zeros(npad, device=DEV)
+    sh = torch.zeros(npad, device=DEV, dtype=torch.bfloat16)
+    pc, gc, mc, vc = p.cpu().clone(), g.cpu().clone(), m.cpu().clone(), v.cpu().clone()
+    shc = sh.cpu().clone()
+    hg = K.OptHyper(DEV, lr=1e-2, weight_decay=0.01, grad_scale=0.5)
+    hc = K.OptHyper("cpu", lr=1e-2, weight_decay=0.01, grad_scale=0.5)
+    for _ in range(3):
+        hg.tick(); hc.tick()
+        K.adam_apply(p, g, m, v, hg, shadow=sh, mode=mode, n=n)
+        K.adam_apply(pc, gc, mc, vc, hc, shadow=shc, mode=mode, n=n)
+    torch.testing.assert_close(hg.buf.cpu(), hc.buf, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(p.cpu()[:n], pc[:n], rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(m.cpu()[:n], mc[:n], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(v.cpu()[:n], vc[:n], rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(sh.cpu()[:n].float(), shc[:n].float(), rtol=1e-2, atol=1e-2)
+    # untouched tail
+    assert torch.equal(p.cpu()[n:], pc[n:])
+
+
+@pytest.mark.parametrize("n", [5, 4096, 100003])
+@pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_sgdm_matches_reference(n, gdtype, mode):
+    from distributed_tensorflow_amd.ops import optim as K
+    torch.manual_seed(n)
+    npad = (n + 63) // 64 * 64
+    p = torch.randn(npad, device=DEV); g = torch.randn(npad, device=DEV).to(gdtype)
+    vel = torch.zeros(npad, device=DEV)
+    pc, gc, vc = p.cpu().clone(), g.cpu().clone(), vel.cpu().clone()
+    hg = K.OptHyper(DEV, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    hc = K.OptHyper("cpu", lr=0.1, momentum=0.9, weight_decay=1e-4)
+    for _ in range(3):
+        K.sgdm_apply(p, g, vel, hg, mode=mode, n=n)
+        K.sgdm_apply(pc, gc, vc, hc, mode=mode, n=n)
+    torch.testing.assert_close(p.cpu()[:n], pc[:n], rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(vel.cpu()[:n], vc[:n], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fdtype", [torch.float32, torch.bfloat16])
+def test_bucket_flatten_unflatten(tdtype, fdtype):
+    from distributed_tensorflow_amd.ops import bucket as B
+    torch.manual_seed(0)
+    shapes = [(3,), (64, 3, 7, 7), (1000, 2048), (17,), (512,), (10, 512), (1,)] + [(33, 5)] * 60
+    ts = [torch.randn(s, device=DEV).to(tdtype) for s in shapes]
+    offs, o = [], 0
+    for t in ts:
+        offs.append(o); o += (t.numel() + 63) // 64 * 64
+    flat = torch.full((o,), 7.0, device=DEV, dtype=fdtype)
+    B.flatten(ts, flat, offs, scale=0.25)
+    for t, off in zip(ts, offs):
+        ref = (t.float() * 0.25).to(fdtype).reshape(-1)
+        assert torch.equal(flat[off:off + t.numel()], ref)
+    outs = [torch.zeros_like(t) for t in ts]
+    B.unflatten(flat, outs, offs, scale=4.0)
+    for t, u, off in zip(ts, outs, offs):
+        ref = (flat[off:off + t.numel()].float() * 4.0).to(tdtype).reshape(t.shape)
+        assert torch.equal(u, ref)
+    # unaligned source pointer takes the scalar path
+    base = torch.randn(1001, device=DEV).to(tdtype)
+    flat2 = torch.zeros(1024, device=DEV, dtype=fdtype)
+    B.flatten([base[1:]], flat2, [0])
+    assert torch.equal(flat2[:1000], base[1:].float().to(fdtype))
+
+
+def test_scale_cast_nary_sumsq():
+    from distributed_tensorflow_amd.ops import bucket as B
+    torch.manual_seed(1)
+    n = 100003 + 5
+    n = n // 8 * 8 + 3
+    a = torch.randn(n, device=DEV)
+    out = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    s = torch.tensor([0.5], device=DEV)
+    B.scale_cast(a, out, 2.0, s)
+    assert torch.equal(out, a.to(torch.bfloat16))
+    for dt in (torch.float32, torch.bfloat16):
+        dst = torch.randn(n, device=DEV).to(dt)
+        srcs = [torch.randn(n, device=DEV).to(dt) for _ in range(7)]
+        ws = [0.125 * (i + 1) for i in range(7)]
+        ref = dst.float() * 0.5
+        for s_, w in zip(srcs, ws):
+            ref = torch.addcmul(ref, s_.float(), torch.tensor(w, device=DEV))
+        B.nary_axpy(dst, srcs, ws, w_dst=0.5)
+        torch.testing.assert_close(dst.float(), ref.to(dt).float(), rtol=1e-2 if dt == torch.bfloat16 else 1e-5,
+                                   atol=1e-2 if dt == torch.bfloat16 else 1e-5)
+    x = torch.randn(n, device=DEV)
+    torch.testing.assert_close(B.sumsq(x)[0], (x.double() ** 2).sum().float(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B_,C", [(100, 10), (7, 3), (64, 1000), (33, 1001), (16, 30522), (5, 65), (300, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ldt", [torch.int64, torch.int32])
+def test_softmax_ce_fwd_bwd(B_, C, dtype, ldt):
+    from distributed_tensorflow_amd.ops.softmax_ce import softmax_ce_eval, softmax_cross_entropy
+    torch.manual_seed(B_ * C)
+    x = (torch.randn(B_, C, device=DEV) * 3).to(dtype).requires_grad_(True)
+    y = torch.randint(0, C, (B_,), device=DEV).to(ldt)
+    y[0] = -100
+    g = torch.rand(B_, device=DEV) + 0.5
+    loss = softmax_cross_entropy(x, y)
+    loss.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, y.long(), reduction="none", ignore_index=-100)
+    ref.backward(g)
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(loss, ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(x.grad.float(), xr.grad, **tol)
+    l2, corr = softmax_ce_eval(x.detach(), y)
+    torch.testing.assert_close(l2, ref.detach(), rtol=1e-4, atol=1e-4)
+    exp_corr = (x.detach().float().argmax(1) == y.long())
+    assert torch.equal(corr.bool(), exp_corr)
+
+
+def _asym(M, N, K, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    return a.to(DEV).to(torch.bfloat16), b.to(DEV).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (100, 512, 784), (256, 512, 8), (300, 264, 200), (1024, 1024, 1024),
+                                   (50, 8, 4096), (4096, 64, 256)])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_gemm_layouts(M, N, K, splits):
+    from distributed_tensorflow_amd.ops import gemm
+    a, b = _asym(M, N, K, M + N + K)
+    af, bf = a.float(), b.float()
+    tol = dict(rtol=2e-2, atol=2e-2 * math.sqrt(K))
+    ref = af @ bf.t()
+    # NT with identity check of orientation: asymmetric operands
+    out = gemm.gemm_nt(a, b, splits=splits)
+    torch.testing.assert_close(out.float(), ref, **tol)
+    bias = torch.randn(N, device=DEV)
+    out = gemm.gemm_nt(a, b, bias=bias, activation="relu", splits=splits, out_dtype=torch.float32)
+    torch.testing.assert_close(out, torch.relu(ref + bias), rtol=1e-2, atol=1e-2 * math.sqrt(K))
+    out = gemm.gemm_nt(a, b, bias=bias.to(torch.bfloat16), activation="gelu", splits=splits)
+    torch.testing.assert_close(out.float(), torch.nn.functional.gelu(ref + bias.to(torch.bfloat16).float()), **tol)
+    if M % 8 == 0:
+        # NN: [M,K] @ [K,N]  with b^T stored as [K,N]
+        bt = b.t().contiguous()          # [K, N]
+        out = gemm.gemm_nn(a, bt, splits=splits)
+        torch.testing.assert_close(out.float(), ref, **tol)
+        # TN: a^T stored [K,M], b^T stored [K,N]
+        at = a.t().contiguous()
+        out = gemm.gemm_tn(at, bt, splits=splits)
+        torch.testing.assert_close(out.float(), ref, **tol)
+
+
+def test_gemm_identity_orientation():
+    from distributed_tensorflow_amd.ops import gemm
+    n = 128
+    eye = torch.eye(n, device=DEV, dtype=torch.bfloat16)
+    b = (torch.arange(n * n, device=DEV).reshape(n, n) % 251).to(torch.bfloat16)  # asymmetric, exact in bf16
+    out = gemm.gemm_nt(eye, b)       # I @ b^T
+    assert torch.equal(out, b.t().contiguous())
+    out = gemm.gemm_nn(eye, b)       # I @ b
+    assert torch.equal(out, b)
+    out = gemm.gemm_tn(eye, b)       # I^T @ b
+    assert torch.equal(out, b)
+
+
+def test_dense_autograd_matches_torch():
+    from distributed_tensorflow_amd.ops.dense import linear
+    torch.manual_seed(0)
+    for act in (None, "relu", "gelu"):
+        x = torch.randn(96, 784, device=DEV).to(torch.bfloat16).requires_grad_(True)
+        w = (torch.randn(512, 784, device=DEV) * 0.05).to(torch.bfloat16).requires_grad_(True)
+        b = torch.randn(512, device=DEV).to(torch.bfloat16).requires_grad_(True)
+        y = linear(x, w, b, act)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+        yr = torch.nn.functional.linear(xr, wr, br)
+        yr = torch.relu(yr) if act == "relu" else torch.nn.functional.gelu(yr) if act == "gelu" else yr
+        yr.backward(gy.float())
+        torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=5e-2)
+        torch.testing.assert_close(x.grad.float(), xr.grad, rtol=3e-2, atol=8e-2)
+        torch.testing.assert_close(w.grad.float(), wr.grad, rtol=3e-2, atol=3e-1)
+        torch.testing.assert_close(b.grad.float(), br.grad, rtol=3e-2, atol=3e-1)
