@@ -1,0 +1,290 @@
+"""Parameter server and worker over the framed-TCP transport.
+
+This is the centralized topology in the shape the reference gives it: one
+server process listening on ``server_address:6000`` with one service thread
+per worker connection, and ``n_nodes`` worker processes (reference
+centralized/server.py:139-187, centralized/client.py:45-101). It is the
+multi-machine path (``-tt server`` / ``-tt worker -ti k -sa ADDR``) and the
+CPU plumbing mode; on a single GPU node the collective strategies of
+``parallel/ps.py`` replace it.
+
+Protocol, per worker connection (kinds below):
+
+    worker: START {index}                      server: barrier; WEIGHTS(flat fp32 master)
+    worker: TRAIN {version, loss}(flat grads)  server: apply; [sync: barrier]; WEIGHTS
+    worker: END                                server: barrier; thread exits
+
+Differences from the reference, all deliberate:
+  * tensors travel as raw bytes of the flat arenas, not pickled lists;
+  * ``sync`` + ``apply='reduced'`` sums the N gradients and takes ONE optimizer step;
+    ``apply='sequential'`` is the reference behaviour, one apply per worker under the lock, each
+    with its own optimizer state unless one optimizer is shared (server.py:52-55,91-93);
+  * the weights sent after a synchronous round are a single snapshot taken when the barrier
+    trips, so no worker can observe a half-applied next round (server.py:95-96 reads outside
+    the lock);
+  * barriers have a timeout and are aborted when a connection drops, so a dead worker ends
+    the job with an error instead of hanging it (server.py:132-134 keeps looping);
+  * the server replies with trainable parameters only; buffers such as batch-norm statistics
+    stay local to each worker (server.py:96,101 overwrites them).
+"""
+from __future__ import annotations
+
+import inspect
+import os
+import threading
+import time
+
+import torch
+
+from ..api.model import as_model
+from ..comm import tcp
+from ..engine.optimizer import FlatOptimizer
+from ..engine.replica import Replica, TrainConfig
+from ..obs.metrics import MetricsLogger, SupervisorSink
+from ..utils.affinity import pin_to_core
+from ..utils.sync import BarrierBroken, DynamicBarrier
+
+START, WEIGHTS, TRAIN, END, ERROR = 1, 2, 3, 4, 5
+DEFAULT_PORT = 6000
+
+
+def call_dataset_fn(dataset_fn, batch_size, n_nodes=None, **kw):
+    """Calls the user's ``dataset_fn`` with the reference's keyword set, adding ``n_nodes`` when
+    the function accepts it (the reference reads it from a module global that only exists in
+    forked children, reference initializer.py:44,119)."""
+    try:
+        params = inspect.signature(dataset_fn).parameters
+        accepts = "n_nodes" in params or any(p.kind == p.VAR_KEYWORD for p in params.values())
+        kw = {k: v for k, v in kw.items() if k in params or any(p.kind == p.VAR_KEYWORD for p in params.values())}
+    except (TypeError, ValueError):
+        accepts = False
+    if n_nodes is not None:
+        os.environ["DTF_N_NODES"] = str(n_nodes)
+        if accepts:
+            kw["n_nodes"] = n_nodes
+    return dataset_fn(batch_size, **kw)
+
+
+class _ServerState:
+    def __init__(self, replica: Replica, n_nodes: int, sync_mode: str, apply: str, optimizer, barrier_timeout: float):
+        self.replica = replica
+        self.flat = replica.flat
+        self.n = n_nodes
+        self.sync_mode = sync_mode
+        self.apply = apply
+        self.lock = threading.Lock()
+        self.barrier = DynamicBarrier(n_nodes, timeout=barrier_timeout)
+        shared = optimizer is not None or apply == "reduced" or sync_mode == "async"
+        self.shared_opt = FlatOptimizer(self.flat, optimizer) if shared else None
+        self.optimizer_spec = optimizer
+        self.sum_grad = torch.zeros_like(self.flat.grad) if (sync_mode == "sync" and apply == "reduced") else None
+        self.snapshot = self.flat.master.detach().cpu().clone()
+        self.version = 0
+        self.start_time = 0.0
+        self.elapsed = None
+        self.ended = 0
+        self.staleness: list[int] = []
+        self.step_latency: list[float] = []
+        self.errors: list[BaseException] = []
+
+    # barrier actions: run by exactly one thread while the others are still blocked
+    def on_all_started(self):
+        if self.start_time == 0.0:
+            self.start_time = time.time()
+
+    def on_round_complete(self):
+        if self.sum_grad is not None:
+            self.shared_opt.step(grad=self.sum_grad)
+            self.sum_grad.zero_()
+            self.version += 1
+        self.snapshot = self.flat.master.detach().cpu().clone()
+
+    def worker_ended(self):
+        with self.lock:
+            self.ended += 1
+            if self.ended == self.n and self.elapsed is None:
+                self.elapsed = time.time() - self.start_time
+
+
+class _ServiceThread(threading.Thread):
+    """One per worker connection: the reference's ``Server(threading.Thread)`` (server.py:40-136)."""
+
+    def __init__(self, conn: tcp.Connection, st: _ServerState, wid: int):
+        super().__init__(daemon=True, name=f"ps-conn-{wid}")
+        self.conn, self.st, self.wid = conn, st, wid
+        self.opt = st.shared_opt if st.shared_opt is not None else FlatOptimizer(st.flat, st.optimizer_spec)
+        self.grad = torch.empty_like(st.flat.grad, device="cpu")
+
+    def run(self):
+        st = self.st
+        left = False
+        try:
+            while True:
+                kind, meta, payload = self.conn.recv(into=self.grad)
+                if kind == START:
+                    print("start", flush=True)
+                    st.barrier.wait(st.on_all_started)   # all workers said start
+                    st.barrier.wait()                    # all ready to receive
+                    self.conn.send(WEIGHTS, {"version": st.version, "n": st.flat.total}, st.snapshot)
+                elif kind == TRAIN:
+                    t0 = time.time()
+                    g = self.grad.to(st.flat.device) if st.flat.device.type != "cpu" else self.grad
+                    if st.sync_mode == "sync":
+                        with st.lock:
+                            if st.sum_grad is not None:
+                                st.sum_grad.add_(g)
+                            else:
+                                self.opt.step(grad=g)
+                                st.version += 1
+                        st.barrier.wait(st.on_round_complete)  # the completing thread takes ONE snapshot
+                        reply = st.snapshot
+                    else:
+                        with st.lock:
+                            st.staleness.append(st.version - int(meta.get("version", st.version)))
+                            self.opt.step(grad=g)
+                            st.version += 1
+                            reply = st.flat.master.detach().cpu().clone()
+                    self.conn.send(WEIGHTS, {"version": st.version}, reply)
+                    st.step_latency.append(time.time() - t0)
+                elif kind == END:
+                    print("end", flush=True)
+                    st.worker_ended()
+                    st.barrier.leave()
+                    left = True
+                    break
+                else:
+                    print("Received unknown message", flush=True)
+        except tcp.ConnectionClosed as e:
+            print("Connection closed", flush=True)
+            st.errors.append(e)
+            if st.sync_mode == "sync":
+                st.barrier.abort()       # a synchronous round can never complete without this worker
+            elif not left:
+                st.worker_ended()        # asynchronous mode tolerates a departed worker
+        except BarrierBroken as e:
+            st.errors.append(e)
+        except BaseException as e:
+            st.errors.append(e)
+            st.barrier.abort()
+        finally:
+            self.conn.close()
+
+
+def start(sync_mode, model_fn, dataset_fn, n_nodes, optimizer=None, supervisor_address=None, cpu_affinity=False,
+          server_address="127.0.0.1", port: int = DEFAULT_PORT, apply: str = "reduced", device="cpu",
+          cfg: TrainConfig | None = None, barrier_timeout: float = 600.0, accept_timeout: float = 600.0,
+          result_queue=None, metrics_path: str | None = None, evaluate: bool = True, ready_event=None) -> dict:
+    """Runs the parameter server until every worker has sent ``end``; then evaluates on the test
+    split and prints the reference's two result lines. Signature follows reference
+    centralized/server.py:139-140."""
+    if sync_mode not in ("sync", "async"):
+        raise ValueError("Invalid centralized strategy")
+    if cpu_affinity:
+        pin_to_core(0)
+    cfg = cfg or TrainConfig(loss_reduction="sum")
+    torch.manual_seed(cfg.seed)
+    replica = Replica(as_model(model_fn()), device, cfg)
+    replica.reducer.detach()
+    st = _ServerState(replica, n_nodes, sync_mode, apply, optimizer, barrier_timeout)
+    sup = SupervisorSink(supervisor_address)
+    sup.send("start")
+    listener = tcp.Listener(server_address, port, backlog=50)
+    if ready_event is not None:
+        ready_event.set()
+    print("accepting", flush=True)
+    threads = []
+    try:
+        for wid in range(n_nodes):
+            conn = listener.accept(timeout=accept_timeout, conn_timeout=barrier_timeout)
+            t = _ServiceThread(conn, st, wid)
+            t.start()
+            threads.append(t)
+        for t in threads:
+            t.join()
+    finally:
+        listener.close()
+    fatal = [e for e in st.errors if not (sync_mode == "async" and isinstance(e, tcp.ConnectionClosed))]
+    if fatal:
+        res = {"ok": False, "error": repr(fatal[0])}
+        if result_queue is not None:
+            result_queue.put(("server", dict(res)))
+        raise RuntimeError(f"parameter server stopped: {fatal[0]!r}")
+    print("elapsed time = " + str(st.elapsed), flush=True)
+    sup.send(["done", st.elapsed])
+    if st.elapsed is None:
+        st.elapsed = time.time() - st.start_time
+    res = {"ok": True, "elapsed": st.elapsed, "versions": st.version, "departed_workers": len(st.errors),
+           "mean_staleness": sum(st.staleness) / max(1, len(st.staleness)),
+           "ps_step_latency_ms": 1e3 * sum(st.step_latency) / max(1, len(st.step_latency))}
+    if evaluate:
+        replica.flat.refresh_shadow()
+        test_ds = call_dataset_fn(dataset_fn, 100, n_nodes=n_nodes, type="test", shard=False)
+        loss, acc, _ = replica.evaluate(test_ds)
+        print("Test set accuracy: {:.3%}".format(acc), flush=True)
+        sup.send(["results", acc])
+        res.update(test_accuracy=acc, test_loss=loss)
+    sup.close()
+    if metrics_path:
+        m = MetricsLogger(metrics_path, rank=-1)
+        m.summary(role="server", **res)
+        m.close()
+    if result_queue is not None:
+        result_queue.put(("server", dict(res)))
+    res["weights"] = replica.flat.master.detach().cpu().clone()
+    return res
+
+
+def train(batch_size, model_fn=None, dataset_fn=None, num_epochs=1, index=0, n_nodes=0, cpu_affinity=False,
+          server_address="127.0.0.1", port: int = DEFAULT_PORT, device="cpu", cfg: TrainConfig | None = None,
+          connect_timeout: float = 120.0, io_timeout: float = 600.0, max_steps: int | None = None,
+          result_queue=None, fault_hook=None, metrics_path: str | None = None) -> dict:
+    """A parameter-server worker. Signature follows reference centralized/client.py:45-46."""
+    if cpu_affinity:
+        pin_to_core(index + 1)  # core 0 is the parameter server's
+    batch_size = int(batch_size)
+    conn = tcp.connect(server_address, port, timeout=connect_timeout, retry_interval=0.2, conn_timeout=io_timeout)
+    cfg = cfg or TrainConfig(loss_reduction="sum")
+    torch.manual_seed(cfg.seed + 1 + index)
+    dataset = call_dataset_fn(dataset_fn, batch_size, n_nodes=n_nodes or None, index=index)
+    replica = Replica(as_model(model_fn()), device, cfg)
+    flat = replica.flat
+    metrics = MetricsLogger(metrics_path, rank=index)
+    host = torch.empty(flat.total, dtype=torch.float32)
+    conn.send(START, {"index": index})
+    kind, meta, _ = conn.recv(into=host)
+    if kind != WEIGHTS:
+        raise RuntimeError(f"expected initial weights, got message kind {kind}")
+    flat.load_flat(host.to(flat.device))
+    version = int(meta.get("version", 0))
+    iteration = 0
+    last = None
+    dev = torch.device(device)
+    try:
+        for _ in range(num_epochs):
+            for x, y in dataset.iterate(dev):
+                if max_steps is not None and iteration >= max_steps:
+                    break
+                if fault_hook is not None:
+                    fault_hook(index, iteration)
+                t0 = time.time()
+                last = replica.forward_backward(x, y, None, 1.0)
+                replica.finish_backward()
+                conn.send(TRAIN, {"version": version, "loss": float(last)}, flat.grad)
+                kind, meta, _ = conn.recv(into=host)
+                if kind != WEIGHTS:
+                    raise RuntimeError(f"expected weights, got message kind {kind}")
+                flat.load_flat(host.to(flat.device))
+                version = int(meta.get("version", version))
+                if iteration % 50 == 0:
+                    print(iteration, flush=True)
+                if metrics.enabled:
+                    metrics.log(step=iteration, loss=float(last), step_s=time.time() - t0, version=version)
+                iteration += 1
+        conn.send(END, {})
+    finally:
+        conn.close()
+        metrics.close()
+    res = {"ok": True, "steps": iteration, "loss": float(last) if last is not None else None}
+    if result_queue is not None:
+        result_queue.put((f"worker{index}", dict(res)))
+    return res

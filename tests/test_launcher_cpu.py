@@ -1,0 +1,124 @@
+"""Launcher contract: flags, dispatch and end-to-end multi-process runs on CPU (gloo / TCP)."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from distributed_tensorflow_amd.cli import launcher  # noqa: E402
+
+
+def test_flag_names_and_defaults_match_reference_contract():
+    p = launcher.build_parser()
+    a = p.parse_args([])
+    assert a.mode is None and a.centralized_strategy is None and a.decentralized_strategy is None
+    assert a.n_nodes is None and a.batch_size == 100
+    assert a.task_type is None and a.task_index is None
+    assert a.server_address == "127.0.0.1" and a.cpu_affinity is False
+    a = p.parse_args("-m c -cs sync -ds keras -n 3 -b 64 -tt worker -ti 2 -sa 10.0.0.1 -ca y -d 4".split())
+    assert (a.mode, a.centralized_strategy, a.decentralized_strategy) == ("c", "sync", "keras")
+    assert (a.n_nodes, a.batch_size, a.task_type, a.task_index) == (3, 64, "worker", 2)
+    assert a.server_address == "10.0.0.1" and a.cpu_affinity is True and a.degree == 4
+
+
+@pytest.mark.parametrize("v,exp", [("yes", True), ("true", True), ("t", True), ("y", True), ("1", True),
+                                   ("no", False), ("false", False), ("f", False), ("n", False), ("0", False),
+                                   (True, True)])
+def test_str2bool(v, exp):
+    assert launcher.str2bool(v) is exp
+
+
+def test_str2bool_rejects_garbage():
+    with pytest.raises(argparse.ArgumentTypeError):
+        launcher.str2bool("maybe")
+
+
+def _args(s):
+    return launcher.build_parser().parse_args(s.split())
+
+
+def test_invalid_mode_and_strategy_raise_value_error():
+    with pytest.raises(ValueError, match="Invalid mode"):
+        launcher.run(_args("-m x -n 1"), None, None)
+    with pytest.raises(ValueError, match="Invalid centralized strategy"):
+        launcher.run(_args("-m c -cs nope -n 1"), None, None)
+    with pytest.raises(ValueError, match="Invalid decentralized strategy"):
+        launcher.run(_args("-m d -ds nope -n 1"), None, None)
+
+
+ENV = dict(os.environ, DTF_SYNTH_MNIST_TRAIN="2000", DTF_SYNTH_MNIST_TEST="400", OMP_NUM_THREADS="2",
+           PYTHONPATH=ROOT)
+
+
+def _launch(flags, tmp_path, timeout=240):
+    res = tmp_path / "res.json"
+    cmd = [sys.executable, os.path.join(ROOT, "initializer.py"), *flags.split(), "--device", "cpu", "--results", str(res)]
+    p = subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    return p.stdout, json.loads(res.read_text())
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("flags,port", [
+    ("-m c -cs sync -n 2 -b 50 --transport tcp -ca y", 6201),
+    ("-m c -cs async -n 2 -b 50 --transport tcp", 6202),
+    ("-m c -cs sync -n 2 -b 50 --transport tcp --apply sequential", 6203),
+])
+def test_centralized_tcp_end_to_end(flags, port, tmp_path):
+    out, res = _launch(f"{flags} --port {port}", tmp_path)
+    assert "elapsed time = " in out and "Test set accuracy: " in out   # the reference's two result lines
+    assert res["ok"] and res["exit_codes"] == [0, 0, 0]               # 1 server + 2 workers
+    assert res["server"]["test_accuracy"] > 0.3
+    assert res["worker0"]["steps"] == 20 and res["worker1"]["steps"] == 20
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("flags", [
+    "-m c -cs sync -n 2 -b 50 --transport collective",
+    "-m c -cs sync -n 2 -b 50 --transport collective --apply sequential",
+    "-m c -cs async -n 2 -b 50 --transport collective",
+    "-m c -cs async -n 2 -b 50 --transport collective --placement dedicated",
+    "-m d -ds keras -n 2 -b 50",
+    "-m d -ds custom -n 2 -b 50 --algorithm direct",
+    "-m d -ds graph -n 3 -b 50 -d 2",
+])
+def test_collective_strategies_end_to_end(flags, tmp_path):
+    out, res = _launch(flags, tmp_path)
+    assert res["ok"] and all(c == 0 for c in res["exit_codes"])
+    if "-m d" in flags:
+        assert "elapsed time: " in out and "eval: " in out
+        accs = [v["test_accuracy"] for k, v in res.items() if k.startswith("rank")]
+        assert len(set(round(a, 6) for a in accs)) == 1   # replicas agree on the final model
+        assert accs[0] > 0.5
+    else:
+        assert "Test set accuracy: " in out
+
+
+@pytest.mark.slow
+def test_worker_failure_ends_sync_job_with_error(tmp_path):
+    """A worker killed mid-run must end the job with a non-zero exit, not hang it (the reference
+    hangs in barrier.wait(), reference centralized/server.py:95)."""
+    cmd = [sys.executable, os.path.join(ROOT, "initializer.py"), *"-m c -cs sync -n 2 -b 50 --transport tcp --port 6210".split(),
+           "--device", "cpu", "--fault-inject", "1:3"]
+    p = subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert p.returncode != 0
+
+
+@pytest.mark.slow
+def test_multi_machine_roles(tmp_path):
+    """-tt server / -tt worker -ti k -sa ADDR (reference initializer.py:147-155), run as separate commands."""
+    base = [sys.executable, os.path.join(ROOT, "initializer.py"), "-m", "c", "-cs", "sync", "-n", "2", "-b", "50",
+            "-sa", "127.0.0.1", "--port", "6220", "--device", "cpu"]
+    srv = subprocess.Popen(base + ["-tt", "server"], env=ENV, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
+    ws = [subprocess.Popen(base + ["-tt", "worker", "-ti", str(i)], env=ENV, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, cwd=ROOT) for i in range(2)]
+    outs = [w.communicate(timeout=200)[0] for w in ws]
+    sout = srv.communicate(timeout=200)[0]
+    assert srv.returncode == 0, sout[-2000:]
+    assert all(w.returncode == 0 for w in ws), outs
+    assert "Test set accuracy: " in sout
