@@ -1,0 +1,102 @@
+"""Headline benchmark: ResNet-50 synchronous data-parallel training throughput (images/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Configuration (the one BASELINE.json names): ResNet-50, synthetic 224x224 images, bf16 compute,
+decentralized keras-style mirrored all-reduce, one process per GPU over RCCL. Weak scaling: the
+per-GPU batch is fixed, the global batch grows with N. A step is forward + backward + bucketed
+gradient all-reduce + optimizer update; nothing is skipped inside the timed region.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DTF_BENCH_BATCH", "256")), help="per-GPU batch")
+    ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--bucket-mb", type=int, default=48)
+    ap.add_argument("--conv1x1", default=None, choices=[None, "gemm", "library"])
+    ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"], help="cpu is for plumbing tests only")
+    ap.add_argument("--model", default="resnet50")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.device == "gpu":
+        if not torch.cuda.is_available():
+            print("bench.py needs a GPU (use --device cpu only for plumbing tests)", file=sys.stderr)
+            return 2
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device("cpu")
+
+    from distributed_tensorflow_amd import bench_lib
+    from distributed_tensorflow_amd.comm.backend import Comm
+    from distributed_tensorflow_amd.ops import _lib, conv
+
+    if dev.type == "cuda":
+        _lib.kernels()
+    if a.conv1x1:
+        conv.set_conv1x1_backend(a.conv1x1)
+    comm = Comm.from_env(dev) if world > 1 else Comm(0, 1, dev)
+    st = bench_lib.make_resnet50_strategy(comm, bucket_mb=a.bucket_mb)
+    x, y = bench_lib.synthetic_imagenet_batch(a.batch, dev, size=a.image, seed=rank)
+
+    def sync():
+        comm.barrier()
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        st.train_step(x, y)
+    sync()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(a.steps):
+        loss = st.train_step(x, y)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64 if dev.type == "cpu" else torch.float32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_v = float(loss)
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = a.batch * world * a.steps / dt
+        print(json.dumps({
+            "metric": "images/sec (whole node) ResNet-50 sync DP", "value": round(value, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"model": "resnet50", "global_batch": a.batch * world, "per_gpu_batch": a.batch,
+                       "image": a.image, "seq_len": None, "parallelism": f"dp{world}",
+                       "strategy": "decentralized keras-style mirrored all-reduce (bucketed, overlapped)",
+                       "optimizer": "sgd-momentum (fused flat-arena kernel)", "conv1x1": conv.get_conv1x1_backend()},
+            "final_loss": loss_v,
+        }), flush=True)
+    comm.shutdown()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

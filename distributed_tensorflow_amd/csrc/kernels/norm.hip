@@ -1,0 +1,253 @@
+// Batch normalisation for NHWC bf16 activations, fused with the residual add and ReLU (gfx950).
+//
+// A convolution output x is viewed as a row-major [M = N*H*W, C] matrix. Training forward is
+// two memory passes instead of the separate normalise / add / relu kernels of an unfused graph:
+//   pass 1  bn_partial_kernel<0>  : per-block partial sum(x), sum(x^2) per channel
+//           bn_finalize_fwd       : mean, 1/std, running-stat update, scale/shift vectors
+//   pass 2  bn_apply_fwd_kernel   : y = relu(x * scale + shift + residual)
+// and backward likewise:
+//   pass 1  bn_partial_kernel<1>  : partial sum(dy'), sum(dy' * xhat),  dy' = dy * (y > 0)
+//           bn_finalize_bwd       : dgamma, dbeta and the three coefficient vectors of dx
+//   pass 2  bn_apply_bwd_kernel   : dx = A*dy' + K*x + C0   (and d_residual = dy')
+// Every thread owns 8 consecutive channels (one 16-byte load) of a row; C/8 threads span a row
+// and the remaining threads of the 256-thread block take further rows. Partial sums are
+// reduced across the block's row lanes through LDS, written per block, and summed in fixed
+// order by the finalize kernel, so results are bitwise reproducible (no float atomics).
+// These are the BatchNorm + ReLU ops of the ResNet configurations; the reference model has
+// no normalisation layer (reference initializer.py:12-21).
+#include "dtf_common.h"
+
+using namespace dtf;
+
+constexpr int kBnMaxPartials = 1024;
+
+__device__ __forceinline__ void ld8bf(const unsigned short* p, float (&o)[8]) {
+  u16x8 a = *reinterpret_cast<const u16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(a[i]);
+}
+__device__ __forceinline__ void st8bf(unsigned short* p, const float (&o)[8]) {
+  u16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = f32_to_bf16(o[i]);
+  *reinterpret_cast<u16x8*>(p) = a;
+}
+__device__ __forceinline__ void ld8f(const float* p, float (&o)[8]) {
+  f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+
+// MODE 0: s0 = sum x, s1 = sum x^2
+// MODE 1: s0 = sum dy', s1 = sum dy' * (x - mean) * invstd,  dy' = relu ? dy * (y > 0) : dy
+// grid = (n_partials, channel_chunks); a channel chunk is up to 2048 channels (256 threads x 8).
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short* __restrict__ x,
+                                                            const unsigned short* __restrict__ dy,
+                                                            const unsigned short* __restrict__ y,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ part,
+                                                            long long M, int C, int relu) {
+  __shared__ float red[2][kBlock][8];
+  const int cchunk = min(C, 2048);
+  const int tpr = cchunk >> 3;                 // threads per row
+  const int rpb = kBlock / tpr;                // rows per block pass
+  const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+  const int c0 = blockIdx.y * 2048 + tc * 8;
+  const bool live = tr < rpb && c0 < C;
+  float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float mu[8], is[8];
+  if (MODE == 1 && live) { ld8f(mean + c0, mu); ld8f(invstd + c0, is); }
+  if (live) {
+    const long long rstride = (long long)gridDim.x * rpb;
+    for (long long r = (long long)blockIdx.x * rpb + tr; r < M; r += rstride) {
+      float v[8];
+      ld8bf(x + r * C + c0, v);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s0[k] += v[k]; s1[k] = fmaf(v[k], v[k], s1[k]); }
+      } else {
+        float g[8];
+        ld8bf(dy + r * C + c0, g);
+        if (relu) {
+          float o[8];
+          ld8bf(y + r * C + c0, o);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s0[k] += g[k]; s1[k] = fmaf(g[k], (v[k] - mu[k]) * is[k], s1[k]); }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][threadIdx.x][k] = s0[k]; red[1][threadIdx.x][k] = s1[k]; }
+  __syncthreads();
+  if (tr == 0 && c0 < C) {
+    for (int r = 1; r < rpb; ++r) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s0[k] += red[0][r * tpr + tc][k]; s1[k] += red[1][r * tpr + tc][k]; }
+    }
+    float* p0 = part + ((long long)blockIdx.x * 2) * C + c0;
+    float* p1 = p0 + C;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { p0[k] = s0[k]; p1[k] = s1[k]; }
+  }
+}
+
+// One thread per channel. Writes mean, invstd, scale = gamma*invstd, shift = beta - mean*scale,
+// and folds the batch statistics into the running ones (unbiased variance, torch convention).
+__global__ void bn_finalize_fwd_kernel(const float* __restrict__ part, int n_part, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ run_mean,
+                                       float* __restrict__ run_var, float* __restrict__ mean,
+                                       float* __restrict__ invstd, float* __restrict__ scale,
+                                       float* __restrict__ shift, long long M, int C, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int p = 0; p < n_part; ++p) { s0 += part[(long long)p * 2 * C + c]; s1 += part[(long long)p * 2 * C + C + c]; }
+  const float inv_m = 1.f / (float)M;
+  const float mu = s0 * inv_m;
+  const float var = fmaxf(s1 * inv_m - mu * mu, 0.f);
+  const float is = rsqrtf(var + eps);
+  mean[c] = mu; invstd[c] = is;
+  const float a = gamma[c] * is;
+  scale[c] = a; shift[c] = beta[c] - mu * a;
+  if (run_mean) {
+    const float unbiased = M > 1 ? var * (float)M / (float)(M - 1) : var;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unbiased;
+  }
+}
+
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ part, int n_part, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cA,
+                                       float* __restrict__ cK, float* __restrict__ c0, long long M, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int p = 0; p < n_part; ++p) { s0 += part[(long long)p * 2 * C + c]; s1 += part[(long long)p * 2 * C + C + c]; }
+  dbeta[c] = s0; dgamma[c] = s1;
+  const float inv_m = 1.f / (float)M;
+  const float a = gamma[c] * invstd[c];
+  const float k = a * s1 * inv_m * invstd[c];     // dx = a*dy' - a*dbeta/M - (x - mean)*k
+  cA[c] = a; cK[c] = -k; c0[c] = mean[c] * k - a * s0 * inv_m;
+}
+
+// y = act(x*scale + shift (+ res))
+__global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(const unsigned short* __restrict__ x,
+                                                              const unsigned short* __restrict__ res,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              unsigned short* __restrict__ y, long long M, int C,
+                                                              int relu) {
+  const long long n8 = M * (C >> 3);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int c8 = C >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const int c = (int)(i % c8) << 3;
+    float v[8], a[8], b[8];
+    ld8bf(x + i * 8, v); ld8f(scale + c, a); ld8f(shift + c, b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], a[k], b[k]);
+    if (res) {
+      float r[8];
+      ld8bf(res + i * 8, r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += r[k];
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    st8bf(y + i * 8, v);
+  }
+}
+
+// dx = A*dy' + K*x + C0 ; dres = dy' (only written when dres != null)
+__global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(const unsigned short* __restrict__ x,
+                                                              const unsigned short* __restrict__ dy,
+                                                              const unsigned short* __restrict__ y,
+                                                              const float* __restrict__ cA, const float* __restrict__ cK,
+                                                              const float* __restrict__ c0,
+                                                              unsigned short* __restrict__ dx,
+                                                              unsigned short* __restrict__ dres, long long M, int C,
+                                                              int relu) {
+  const long long n8 = M * (C >> 3);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int c8 = C >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const int c = (int)(i % c8) << 3;
+    float v[8], g[8], a[8], kk[8], z[8];
+    ld8bf(x + i * 8, v); ld8bf(dy + i * 8, g);
+    ld8f(cA + c, a); ld8f(cK + c, kk); ld8f(c0 + c, z);
+    if (relu) {
+      float o[8];
+      ld8bf(y + i * 8, o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+    }
+    if (dres) st8bf(dres + i * 8, g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = fmaf(a[k], g[k], fmaf(kk[k], v[k], z[k]));
+    st8bf(dx + i * 8, v);
+  }
+}
+
+static int bn_partials_for(long long M, int C) {
+  const int cchunk = C < 2048 ? C : 2048;
+  const int rpb = kBlock / (cchunk / 8);
+  long long nb = (M + (long long)rpb * 8 - 1) / ((long long)rpb * 8);   // >= 8 passes per block
+  const int cy = (C + 2047) / 2048;
+  long long cap = kBnMaxPartials / cy;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+DTF_API int dtf_bn_num_partials(long long M, int C) { return bn_partials_for(M, C); }
+
+// workspace: fp32 [n_partials * 2 * C]. stats: mean, invstd, scale, shift each [C] fp32.
+DTF_API int dtf_bn_fwd_train(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                             float* run_mean, float* run_var, float* mean, float* invstd, float* scale, float* shift,
+                             float* workspace, long long M, int C, float eps, float momentum, int relu,
+                             hipStream_t stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (C % 8) return -1;
+  const int nb = bn_partials_for(M, C);
+  const dim3 grid(nb, (C + 2047) / 2048);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, grid, dim3(kBlock), 0, stream, (const unsigned short*)x, nullptr, nullptr,
+                     nullptr, nullptr, workspace, M, C, 0);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, workspace, nb, gamma, beta,
+                     run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y, M, C, relu);
+  return (int)hipGetLastError();
+}
+
+DTF_API int dtf_bn_fwd_apply(const void* x, const void* res, void* y, const float* scale, const float* shift,
+                             long long M, int C, int relu, hipStream_t stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (C % 8) return -1;
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y, M, C, relu);
+  return (int)hipGetLastError();
+}
+
+// coef: fp32 [3 * C] scratch (A, K, C0).
+DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* mean,
+                       const float* invstd, void* dx, void* dres, float* dgamma, float* dbeta, float* coef,
+                       float* workspace, long long M, int C, int relu, hipStream_t stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (C % 8) return -1;
+  const int nb = bn_partials_for(M, C);
+  const dim3 grid(nb, (C + 2047) / 2048);
+  hipLaunchKernelGGL(bn_partial_kernel<1>, grid, dim3(kBlock), 0, stream, (const unsigned short*)x,
+                     (const unsigned short*)dy, (const unsigned short*)y, mean, invstd, workspace, M, C, relu);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, workspace, nb, gamma, mean,
+                     invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C);
+  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+                     (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,
+                     coef + 2 * C, (unsigned short*)dx, (unsigned short*)dres, M, C, relu);
+  return (int)hipGetLastError();
+}

@@ -86,7 +86,7 @@ class GradReducer:
             if g is None:
                 missing.append(s)
                 continue
-            if tuple(g.stride()) != s.stride:
+            if any(gs != ss for gs, ss, n in zip(g.stride(), s.stride, s.shape) if n != 1):
                 g = torch.empty_strided(tuple(s.shape), s.stride, dtype=g.dtype, device=g.device).copy_(g)
             ts, offs = groups.setdefault(g.dtype, ([], []))
             ts.append(g)
@@ -95,8 +95,8 @@ class GradReducer:
         for s in missing:  # parameter took no part in this step
             flat.grad[s.offset:s.offset + s.numel].zero_()
         for dt, (ts, offs) in groups.items():
-            bops.flatten([t.as_strided((t.numel(),), (1,)) if not t.is_contiguous() else t.reshape(-1)
-                          for t in ts], flat.grad, offs, scale=self.grad_scale)
+            # every gradient is a dense block laid out like its parameter: pack its raw memory order
+            bops.flatten([t.as_strided((t.numel(),), (1,)) for t in ts], flat.grad, offs, scale=self.grad_scale)
 
     # ---------------------------------------------------------------- finish
     def finish(self) -> list[Any]:

@@ -1,0 +1,200 @@
+"""ResNet-20 (CIFAR-10) and ResNet-50 (ImageNet), NHWC / bf16 first.
+
+The reference ships only an MLP (reference initializer.py:12-21); these are the
+convolutional models of the named benchmark configurations (CIFAR-10 ResNet-20
+under the asynchronous parameter server, ResNet-50 under the mirrored
+all-reduce strategy).
+
+Layout: activations are ``channels_last`` (physically NHWC) end to end and
+convolution weights are stored ``channels_last`` too, so no layout transposes
+are inserted around the convolutions. Every convolution is followed by
+``BNAct``: batch normalisation fused with the optional residual add and ReLU
+into two memory passes forward and two backward (``ops/norm.py``), instead of
+separate normalise / add / activation kernels.
+
+Keras weight export order: per layer ``kernel (HWIO)`` then ``gamma, beta,
+moving_mean, moving_variance``, as ``keras.applications``-style models list them.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..api.model import Model
+from ..ops import conv as conv_ops
+from ..ops import dense as dense_ops
+from ..ops import norm as norm_ops
+
+
+class Conv(nn.Module):
+    """Bias-free 2-D convolution with channels_last weights (He-normal init, fan-out)."""
+
+    def __init__(self, cin: int, cout: int, k: int, stride: int = 1, padding: int | None = None):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride = cin, cout, k, stride
+        self.padding = (k // 2) if padding is None else padding
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+
+    def forward(self, x):
+        return conv_ops.conv2d(x, self.weight, self.stride, self.padding)
+
+    def keras_weights(self):
+        return [np.ascontiguousarray(self.weight.detach().float().cpu().numpy().transpose(2, 3, 1, 0))]
+
+    def set_keras_weights(self, ws):
+        a = torch.from_numpy(np.ascontiguousarray(np.asarray(ws[0]).transpose(3, 2, 0, 1)))
+        with torch.no_grad():
+            self.weight.copy_(a.to(self.weight.dtype))
+        return 1
+
+
+class BNAct(nn.Module):
+    """Batch normalisation (+ residual add) (+ ReLU) over the channel axis; parameters and running
+    statistics stay fp32 whatever the activation dtype."""
+    keep_fp32 = True
+
+    def __init__(self, c: int, relu: bool = True, eps: float = 1e-5, momentum: float = 0.1, zero_init: bool = False):
+        super().__init__()
+        self.c, self.relu, self.eps, self.momentum = c, relu, eps, momentum
+        self.weight = nn.Parameter(torch.zeros(c) if zero_init else torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+
+    def forward(self, x, residual=None):
+        return norm_ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                       self.training, self.momentum, self.eps, self.relu, residual)
+
+    def keras_weights(self):
+        return [t.detach().float().cpu().numpy() for t in (self.weight, self.bias, self.running_mean, self.running_var)]
+
+    def set_keras_weights(self, ws):
+        with torch.no_grad():
+            for t, a in zip((self.weight, self.bias, self.running_mean, self.running_var), ws[:4]):
+                t.copy_(torch.from_numpy(np.asarray(a)).to(t.dtype))
+        return 4
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin: int, width: int, stride: int):
+        super().__init__()
+        cout = width * 4
+        self.conv1, self.bn1 = Conv(cin, width, 1), BNAct(width)
+        self.conv2, self.bn2 = Conv(width, width, 3, stride), BNAct(width)
+        self.conv3, self.bn3 = Conv(width, cout, 1), BNAct(cout, relu=True, zero_init=True)
+        self.down = None
+        if stride != 1 or cin != cout:
+            self.down = Conv(cin, cout, 1, stride)
+            self.down_bn = BNAct(cout, relu=False)
+
+    def forward(self, x):
+        idt = x if self.down is None else self.down_bn(self.down(x))
+        y = self.bn1(self.conv1(x))
+        y = self.bn2(self.conv2(y))
+        return self.bn3(self.conv3(y), residual=idt)   # relu(bn(conv) + identity) in one fused pass
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin: int, cout: int, stride: int):
+        super().__init__()
+        self.conv1, self.bn1 = Conv(cin, cout, 3, stride), BNAct(cout)
+        self.conv2, self.bn2 = Conv(cout, cout, 3), BNAct(cout, relu=True)
+        self.down = None
+        if stride != 1 or cin != cout:
+            self.down = Conv(cin, cout, 1, stride)
+            self.down_bn = BNAct(cout, relu=False)
+
+    def forward(self, x):
+        idt = x if self.down is None else self.down_bn(self.down(x))
+        y = self.bn1(self.conv1(x))
+        return self.bn2(self.conv2(y), residual=idt)
+
+
+class Classifier(nn.Module):
+    """Global average pool + dense layer producing logits (softmax is fused into the loss)."""
+
+    def __init__(self, cin: int, classes: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(classes, cin))
+        nn.init.normal_(self.weight, std=0.01)
+        self.bias = nn.Parameter(torch.zeros(classes))
+
+    def forward(self, x):
+        x = x.mean(dim=(2, 3))
+        return dense_ops.linear(x, self.weight, self.bias)
+
+    def keras_weights(self):
+        return [self.weight.detach().float().cpu().numpy().T.copy(), self.bias.detach().float().cpu().numpy()]
+
+    def set_keras_weights(self, ws):
+        with torch.no_grad():
+            self.weight.copy_(torch.from_numpy(np.asarray(ws[0]).T.copy()).to(self.weight.dtype))
+            self.bias.copy_(torch.from_numpy(np.asarray(ws[1])).to(self.bias.dtype))
+        return 2
+
+
+class ResNet50(Model):
+    supports_logits = True
+    input_layout = "NHWC"
+
+    def __init__(self, classes: int = 1000, layers=(3, 4, 6, 3), width: int = 64):
+        super().__init__()
+        self.stem, self.stem_bn = Conv(3, width, 7, 2, 3), BNAct(width)
+        blocks = []
+        cin = width
+        for i, n in enumerate(layers):
+            w = width * (2 ** i)
+            for j in range(n):
+                blocks.append(Bottleneck(cin, w, 2 if (j == 0 and i > 0) else 1))
+                cin = w * 4
+        self.blocks = nn.Sequential(*blocks)
+        self.head = Classifier(cin, classes)
+
+    def forward(self, x, logits: bool = False):
+        x = self.prepare_input(x)
+        x = self.stem_bn(self.stem(x))
+        x = F.max_pool2d(x, 3, 2, 1)
+        x = self.blocks(x)
+        y = self.head(x)
+        return y if logits else torch.softmax(y.float(), dim=-1)
+
+
+class ResNet20(Model):
+    """The CIFAR-10 ResNet of He et al. (3 stages x 3 basic blocks, 16/32/64 channels, ~0.27 M parameters)."""
+    supports_logits = True
+    input_layout = "NHWC"
+
+    def __init__(self, classes: int = 10, n: int = 3):
+        super().__init__()
+        self.stem, self.stem_bn = Conv(3, 16, 3), BNAct(16)
+        blocks = []
+        cin = 16
+        for i, c in enumerate((16, 32, 64)):
+            for j in range(n):
+                blocks.append(BasicBlock(cin, c, 2 if (j == 0 and i > 0) else 1))
+                cin = c
+        self.blocks = nn.Sequential(*blocks)
+        self.head = Classifier(cin, classes)
+
+    def forward(self, x, logits: bool = False):
+        x = self.prepare_input(x)
+        x = self.stem_bn(self.stem(x))
+        x = self.blocks(x)
+        y = self.head(x)
+        return y if logits else torch.softmax(y.float(), dim=-1)
+
+
+def resnet50(classes: int = 1000) -> ResNet50:
+    return ResNet50(classes)
+
+
+def resnet20(classes: int = 10) -> ResNet20:
+    return ResNet20(classes)

@@ -1,0 +1,103 @@
+"""Batch normalisation fused with residual add and ReLU (front end of ``csrc/kernels/norm.hip``).
+
+``batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
+residual)`` computes ``act(bn(x) + residual)`` for a channels_last bf16 activation in two
+memory passes forward and two backward. fp32 activations, channel counts that are not a
+multiple of 8 and CPU tensors use the equivalent torch composition.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+_ws: dict = {}
+
+
+def _scratch(device, numel: int) -> torch.Tensor:
+    key = (device.type, device.index)
+    t = _ws.get(key)
+    if t is None or t.numel() < numel:
+        t = torch.empty(max(numel, 1 << 21), dtype=torch.float32, device=device)
+        _ws[key] = t
+    return t
+
+
+def _fast_path(x: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _BNActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, relu, residual):
+        N, C, H, W = x.shape
+        M = N * H * W
+        dev = x.device
+        y = torch.empty_like(x)  # preserves channels_last
+        stats = torch.empty(4, C, dtype=torch.float32, device=dev)
+        lib = _lib.kernels()
+        nb = lib.dtf_bn_num_partials(ctypes.c_longlong(M), C)
+        ws = _scratch(dev, nb * 2 * C)
+        if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+            residual = residual.contiguous(memory_format=torch.channels_last)
+        rc = lib.dtf_bn_fwd_train(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta),
+                                  _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
+                                  _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), ctypes.c_longlong(M), C,
+                                  ctypes.c_float(eps), ctypes.c_float(momentum), int(relu), _lib.stream_ptr(dev))
+        _lib.check(rc, "bn_fwd_train")
+        ctx.relu = bool(relu)
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, y if relu else None, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, stats = ctx.saved_tensors
+        N, C, H, W = x.shape
+        M = N * H * W
+        dev = x.device
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        need_dres = ctx.has_res and ctx.relu
+        dres = torch.empty_like(x) if need_dres else None
+        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
+        coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+        lib = _lib.kernels()
+        nb = lib.dtf_bn_num_partials(ctypes.c_longlong(M), C)
+        ws = _scratch(dev, nb * 2 * C)
+        rc = lib.dtf_bn_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(stats[0]),
+                            _lib.ptr(stats[1]), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]),
+                            _lib.ptr(coef), _lib.ptr(ws), ctypes.c_longlong(M), C, int(ctx.relu), _lib.stream_ptr(dev))
+        _lib.check(rc, "bn_bwd")
+        if ctx.has_res and not ctx.relu:
+            dres = dy
+        return dx, dgb[0], dgb[1], None, None, None, None, None, dres
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, momentum: float = 0.1,
+                   eps: float = 1e-5, relu: bool = True, residual=None):
+    if _fast_path(x) and gamma.dtype == torch.float32:
+        if training:
+            return _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual)
+        scale = gamma * torch.rsqrt(running_var + eps)
+        shift = beta - running_mean * scale
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+            residual = residual.contiguous(memory_format=torch.channels_last)
+        rc = _lib.kernels().dtf_bn_fwd_apply(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(scale),
+                                             _lib.ptr(shift), ctypes.c_longlong(N * H * W), C, int(relu),
+                                             _lib.stream_ptr(x.device))
+        _lib.check(rc, "bn_fwd_apply")
+        return y
+    y = F.batch_norm(x.float() if x.dtype != torch.float32 and not x.is_cuda else x, running_mean, running_var,
+                     gamma, beta, training, momentum, eps)
+    y = y.to(x.dtype)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
