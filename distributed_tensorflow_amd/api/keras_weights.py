@@ -147,6 +147,9 @@ def get_weights(module: nn.Module) -> list[np.ndarray]:
 
 def set_weights(module: nn.Module, weights: Sequence[np.ndarray]) -> None:
     ws = list(weights)
+    expected = len(named_weights(module))
+    if len(ws) != expected:
+        raise ValueError(f"set_weights: model takes {expected} arrays, {len(ws)} were given")
     i = 0
     for name, m, kind in _walk(module):
         if kind == "protocol":

@@ -94,17 +94,49 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short
   }
 }
 
-// One thread per channel. Writes mean, invstd, scale = gamma*invstd, shift = beta - mean*scale,
-// and folds the batch statistics into the running ones (unbiased variance, torch convention).
-__global__ void bn_finalize_fwd_kernel(const float* __restrict__ part, int n_part, const float* __restrict__ gamma,
+// Sum of the per-block partials for 32 channels per 256-thread block: lane (c = tid & 31) x
+// partial-lane (tid >> 5) strides over the partials with 4 loads in flight, then the 8
+// partial-lanes are combined through LDS in a fixed order (bitwise reproducible).
+__device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ part, int n_part, int C, float& s0, float& s1) {
+  __shared__ float red[2][8][32];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    int p = pl;
+    for (; p + 24 < n_part; p += 32) {
+      const float* q = part + (long long)p * 2 * C + c;
+      const long long st = (long long)16 * C;   // 8 partials ahead
+      float x0 = q[0], y0 = q[C], x1 = q[st], y1 = q[st + C], x2 = q[2 * st], y2 = q[2 * st + C], x3 = q[3 * st],
+            y3 = q[3 * st + C];
+      a0 += (x0 + x1) + (x2 + x3);
+      a1 += (y0 + y1) + (y2 + y3);
+    }
+    for (; p < n_part; p += 8) {
+      a0 += part[(long long)p * 2 * C + c];
+      a1 += part[(long long)p * 2 * C + C + c];
+    }
+  }
+  red[0][pl][cl] = a0; red[1][pl][cl] = a1;
+  __syncthreads();
+  if (pl != 0 || c >= C) return false;
+  s0 = 0.f; s1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) { s0 += red[0][r][cl]; s1 += red[1][r][cl]; }
+  return true;
+}
+
+// Writes mean, invstd, scale = gamma*invstd, shift = beta - mean*scale, and folds the batch
+// statistics into the running ones (unbiased variance, torch convention). grid = ceil(C / 32).
+__global__ __launch_bounds__(kBlock) void bn_finalize_fwd_kernel(const float* __restrict__ part, int n_part,
+                                       const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* __restrict__ run_mean,
                                        float* __restrict__ run_var, float* __restrict__ mean,
                                        float* __restrict__ invstd, float* __restrict__ scale,
                                        float* __restrict__ shift, long long M, int C, float eps, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s0 = 0.f, s1 = 0.f;
-  for (int p = 0; p < n_part; ++p) { s0 += part[(long long)p * 2 * C + c]; s1 += part[(long long)p * 2 * C + C + c]; }
+  float s0, s1;
+  if (!bn_sum_partials(part, n_part, C, s0, s1)) return;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   const float inv_m = 1.f / (float)M;
   const float mu = s0 * inv_m;
   const float var = fmaxf(s1 * inv_m - mu * mu, 0.f);
@@ -119,14 +151,14 @@ __global__ void bn_finalize_fwd_kernel(const float* __restrict__ part, int n_par
   }
 }
 
-__global__ void bn_finalize_bwd_kernel(const float* __restrict__ part, int n_part, const float* __restrict__ gamma,
+__global__ __launch_bounds__(kBlock) void bn_finalize_bwd_kernel(const float* __restrict__ part, int n_part,
+                                       const float* __restrict__ gamma,
                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cA,
                                        float* __restrict__ cK, float* __restrict__ c0, long long M, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s0 = 0.f, s1 = 0.f;
-  for (int p = 0; p < n_part; ++p) { s0 += part[(long long)p * 2 * C + c]; s1 += part[(long long)p * 2 * C + C + c]; }
+  float s0, s1;
+  if (!bn_sum_partials(part, n_part, C, s0, s1)) return;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   dbeta[c] = s0; dgamma[c] = s1;
   const float inv_m = 1.f / (float)M;
   const float a = gamma[c] * invstd[c];
@@ -218,7 +250,7 @@ DTF_API int dtf_bn_fwd_train(const void* x, const void* res, void* y, const floa
   const dim3 grid(nb, (C + 2047) / 2048);
   hipLaunchKernelGGL(bn_partial_kernel<0>, grid, dim3(kBlock), 0, stream, (const unsigned short*)x, nullptr, nullptr,
                      nullptr, nullptr, workspace, M, C, 0);
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, workspace, nb, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, workspace, nb, gamma, beta,
                      run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y, M, C, relu);
@@ -244,7 +276,7 @@ DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float
   const dim3 grid(nb, (C + 2047) / 2048);
   hipLaunchKernelGGL(bn_partial_kernel<1>, grid, dim3(kBlock), 0, stream, (const unsigned short*)x,
                      (const unsigned short*)dy, (const unsigned short*)y, mean, invstd, workspace, M, C, relu);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, workspace, nb, gamma, mean,
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, workspace, nb, gamma, mean,
                      invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C);
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,

@@ -59,8 +59,8 @@ class SyncPSStrategy(Strategy):
         self.broadcast_initial(0)
         self._scale = 1.0 / W if (self.cfg.loss_reduction == "mean" and apply == "reduced") else 1.0
         if apply == "sequential" and W > 1:
-            biggest = max(b.numel for b in self.planner.buckets) // W
-            self._gathered = torch.empty(W * biggest, dtype=self.flat.grad.dtype, device=comm.device)
+            # room for every worker's copy of this rank's shard of every bucket
+            self._gathered = torch.empty(self.flat.total, dtype=self.flat.grad.dtype, device=comm.device)
         self.bytes_pushed = 0
         self.bytes_pulled = 0
 
@@ -85,17 +85,19 @@ class SyncPSStrategy(Strategy):
             if W == 1:
                 self.optimizer.step(self.shards)
             else:
-                # every owner receives each worker's gradient for its shard, then applies them one
-                # after the other (rank order), as the reference's per-connection threads do
+                # every owner receives each worker's gradient for its shards, then applies them one
+                # worker after the other (rank order), as the reference's per-connection threads do
+                per_worker = [dict() for _ in range(W)]
                 for b, (a, e) in zip(self.planner.buckets, self.shards):
                     n = e - a
-                    g = self._gathered[: W * n]
+                    g = self._gathered[b.start:b.end]
                     self.comm.all_to_all(g, f.grad[b.start:b.end])
                     self.bytes_pushed += (W - 1) * n * f.grad.element_size()
                     for w in range(W):
-                        opt = self.optimizers[w if len(self.optimizers) > 1 else 0]
-                        # address the worker-w copy of this shard with the arena's own indexing
-                        opt.step([(a, e)], grad=_Shifted(g, w * n - a))
+                        per_worker[w][(a, e)] = g[w * n:(w + 1) * n]
+                for w in range(W):
+                    opt = self.optimizers[w if len(self.optimizers) > 1 else 0]
+                    opt.step(self.shards, grad=_Mapped(per_worker[w]))
         # ------------------------------------------------------------- pull
         if W > 1:
             for b, (a, e) in zip(self.planner.buckets, self.shards):
@@ -103,6 +105,16 @@ class SyncPSStrategy(Strategy):
                 self.bytes_pulled += (b.numel - (e - a)) * 4
             f.refresh_shadow()
         return loss
+
+
+class _Mapped:
+    """Gradient source for ``FlatOptimizer.step``: arena range -> the tensor holding it."""
+
+    def __init__(self, table: dict):
+        self.table = table
+
+    def __getitem__(self, s: slice):
+        return self.table[(s.start, s.stop)]
 
 
 class _Shifted:

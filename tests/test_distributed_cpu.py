@@ -1,0 +1,271 @@
+"""Multi-process tests over gloo on loopback: collective algorithms and strategy equivalences."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.slow
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(fn, world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q, args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        r, v = q.get(timeout=240)
+        out[r] = v
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r, v in out.items():
+        assert not (isinstance(v, str) and v.startswith("ERR")), v
+    return [out[r] for r in range(world)]
+
+
+def _entry(fn, rank, world, port, q, args):
+    import traceback
+    torch.set_num_threads(1)
+    sys.path.insert(0, ROOT)
+    try:
+        from distributed_tensorflow_amd.comm.backend import Comm
+        comm = Comm.init(rank, world, "cpu", "127.0.0.1", port, timeout_s=120)
+        res = fn(comm, *args)
+        comm.barrier()
+        q.put((rank, res))
+        comm.shutdown()
+    except BaseException:
+        q.put((rank, "ERR " + traceback.format_exc()))
+        raise
+
+
+# ------------------------------------------------------------------ algorithms
+def _algo_body(comm, algo, n):
+    from distributed_tensorflow_amd.comm import algorithms as A
+    torch.manual_seed(100 + comm.rank)
+    buf = torch.randn(n)
+    mine = buf.clone()
+    A.ALGORITHMS[algo](comm, buf)
+    ref = mine.clone()
+    comm.all_reduce(ref)
+    return float((buf - ref).abs().max()), buf[:64].tolist()
+
+
+@pytest.mark.parametrize("algo", ["direct", "ring", "multiring", "tree", "oneshot"])
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_all_reduce_algorithms_match_the_backend(algo, world):
+    n = 8 * world * 6 * 5 * 7
+    res = _run(_algo_body, world, algo, n)
+    for err, _ in res:
+        assert err < 1e-5
+    # every replica holds bit-identical results
+    assert all(r[1] == res[0][1] for r in res)
+
+
+def _rs_ag_body(comm):
+    from distributed_tensorflow_amd.comm import algorithms as A
+    W = comm.world
+    n = 64 * W
+    buf = torch.arange(n, dtype=torch.float32) * (comm.rank + 1)
+    shard = A.reduce_scatter_direct(comm, buf)
+    c = n // W
+    exp = torch.arange(n, dtype=torch.float32)[comm.rank * c:(comm.rank + 1) * c] * sum(range(1, W + 1))
+    ok1 = torch.equal(shard, exp)
+    A.all_gather_direct(comm, buf)
+    ok2 = torch.equal(buf, torch.arange(n, dtype=torch.float32) * sum(range(1, W + 1)))
+    return ok1 and ok2
+
+
+def test_direct_reduce_scatter_and_all_gather_halves():
+    assert all(_run(_rs_ag_body, 4))
+
+
+# ------------------------------------------------------------------ strategies
+def _make_data(world, rank, per=24, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(world * per, 28, 28, 1, generator=g)
+    y = torch.randint(0, 10, (world * per,), generator=g, dtype=torch.int32)
+    return x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per], x, y
+
+
+def _strategy_body(comm, kind, steps):
+    from distributed_tensorflow_amd.engine.optimizer import Adam
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    from distributed_tensorflow_amd.parallel import mirrored, ps
+    torch.manual_seed(0)
+    model = reference_mlp(dropout=0.0)
+    cfg = TrainConfig(loss_reduction="mean", bucket_bytes=400_000, first_bucket_bytes=30_000)
+    if kind == "keras":
+        st = mirrored.MirroredStrategy(model, comm, cfg, optimizer=Adam())
+    elif kind.startswith("custom"):
+        st = mirrored.CustomAllReduceStrategy(model, comm, cfg, optimizer=Adam(), algorithm=kind.split(":")[1])
+    elif kind == "sync":
+        st = ps.SyncPSStrategy(model, comm, cfg, optimizer=Adam(), apply="reduced")
+    else:
+        raise ValueError(kind)
+    x, y, _, _ = _make_data(comm.world, comm.rank)
+    for _ in range(steps):
+        st.train_step(x, y)
+    used = st.flat.used
+    return st.flat.master[:used].clone().numpy(), [len(st.planner.buckets)]
+
+
+def _single_process_reference(world, steps):
+    from distributed_tensorflow_amd.comm.backend import Comm
+    from distributed_tensorflow_amd.engine.optimizer import Adam
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    from distributed_tensorflow_amd.parallel import mirrored
+    torch.manual_seed(0)
+    st = mirrored.MirroredStrategy(reference_mlp(dropout=0.0), Comm(0, 1, "cpu"), TrainConfig(loss_reduction="mean"),
+                                   optimizer=Adam())
+    _, _, x, y = _make_data(world, 0)
+    for _ in range(steps):
+        st.train_step(x, y)
+    return st.flat
+
+
+@pytest.mark.parametrize("kind", ["keras", "custom:direct", "custom:ring", "custom:tree", "sync"])
+def test_sync_strategies_equal_large_batch_training(kind):
+    """N replicas on 1/N of the batch with averaged gradients == one process on the whole batch."""
+    world, steps = 2, 3
+    res = _run(_strategy_body, world, kind, steps)
+    ref = _single_process_reference(world, steps)
+    # replicas agree bit for bit
+    assert (res[0][0] == res[1][0]).all()
+    assert res[0][1][0] > 1          # really bucketed
+    # and match the single-process run up to summation order; arenas may be padded differently,
+    # so compare parameter by parameter through a fresh FlatParams of each layout
+    got = torch.from_numpy(res[0][0])
+    from distributed_tensorflow_amd.engine.flat import FlatParams
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    ways = 1 if kind == "keras" else world
+    layout = FlatParams.from_module(reference_mlp(dropout=0.0), shard_ways=ways)
+    for s in layout.slots:
+        a = got[s.offset:s.offset + s.numel]
+        rs = ref.by_name[s.name]
+        b = ref.master[rs.offset:rs.offset + rs.numel]
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-6), s.name
+
+
+def _sequential_body(comm, steps):
+    from distributed_tensorflow_amd.engine.optimizer import Adam
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    from distributed_tensorflow_amd.parallel import ps
+    torch.manual_seed(0)
+    st = ps.SyncPSStrategy(reference_mlp(dropout=0.0), comm, TrainConfig(loss_reduction="sum"), optimizer=Adam(),
+                           apply="sequential")
+    x, y, _, _ = _make_data(comm.world, comm.rank)
+    for _ in range(steps):
+        st.train_step(x, y)
+    return st.flat.master[: st.flat.used].clone().numpy()
+
+
+def test_sequential_sync_ps_applies_each_workers_gradient_with_its_own_adam_state():
+    """Reference semantics (reference centralized/server.py:52-55,91-93): per round the shared weights
+    move N times, each move by a separate Adam state that sees only its worker's gradients."""
+    world, steps = 2, 2
+    res = _run(_sequential_body, world, steps)
+    assert (res[0] == res[1]).all()
+    # emulate in one process
+    from distributed_tensorflow_amd.engine.flat import FlatParams
+    from distributed_tensorflow_amd.engine.optimizer import Adam, FlatOptimizer
+    from distributed_tensorflow_amd.engine.replica import Replica, TrainConfig
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    torch.manual_seed(0)
+    srv = Replica(reference_mlp(dropout=0.0), "cpu", TrainConfig(loss_reduction="sum", shard_ways=world))
+    opts = [FlatOptimizer(srv.flat, Adam()) for _ in range(world)]
+    workers = []
+    for r in range(world):
+        torch.manual_seed(0)
+        w = Replica(reference_mlp(dropout=0.0), "cpu", TrainConfig(loss_reduction="sum", shard_ways=world))
+        w.flat.load_flat(srv.flat.master.clone())
+        workers.append(w)
+    for _ in range(steps):
+        for r, w in enumerate(workers):
+            x, y, _, _ = _make_data(world, r)
+            w.forward_backward(x, y); w.finish_backward()
+        for r, w in enumerate(workers):
+            opts[r].step(grad=w.flat.grad)
+        for w in workers:
+            w.flat.load_flat(srv.flat.master.clone())
+    # Adam's m / sqrt(v) amplifies rounding differences on near-zero gradients: compare statistically
+    diff = (torch.from_numpy(res[0]) - srv.flat.master[: srv.flat.used]).abs()
+    assert float((diff < 1e-5).float().mean()) > 0.995 and float(diff.max()) < 4.1e-3
+
+
+def _graph_body(comm, degree):
+    from distributed_tensorflow_amd.engine.optimizer import SGD
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    from distributed_tensorflow_amd.parallel import mirrored
+    torch.manual_seed(0)
+    st = mirrored.GraphStrategy(reference_mlp(dropout=0.0), comm, TrainConfig(), optimizer=SGD(0.05), degree=degree)
+    x, y, _, _ = _make_data(comm.world, comm.rank)
+    total0 = st.flat.master.clone()
+    for _ in range(3):
+        st.train_step(x, y)
+    dis = st.disagreement()
+    st.finalize()
+    return dis, st.disagreement(), sorted(st.neighbours)
+
+
+def test_graph_strategy_gossip_keeps_replicas_close_and_finalize_reaches_consensus():
+    res = _run(_graph_body, 4, 2)
+    for r, (dis, after, nb) in enumerate(res):
+        assert nb == sorted({(r + 1) % 4, (r - 1) % 4})
+        assert 0 < dis < 0.05
+        assert after < 1e-6
+    full = _run(_graph_body, 4, 3)           # complete graph: one gossip step = exact averaging
+    assert all(d < 1e-6 for d, _, _ in full)
+
+
+def _async_body(comm, placement, steps):
+    from distributed_tensorflow_amd.engine.optimizer import Adam
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    from distributed_tensorflow_amd.parallel import ps
+    from distributed_tensorflow_amd.data.dataset import Dataset
+    torch.manual_seed(0)
+    st = ps.AsyncPSStrategy(reference_mlp(dropout=0.0), comm, TrainConfig(loss_reduction="sum"), optimizer=Adam(),
+                            placement=placement)
+    nw = len(st.workers)
+    ds = None
+    if st.is_worker:
+        x, y, _, _ = _make_data(nw, st.workers.index(comm.rank), per=steps * 8)
+        ds = Dataset.from_tensor_slices((x, y)).batch(8)
+    before = st.flat.master.clone()
+    out = st.run_epochs(ds)
+    moved = float((st.flat.master - before).abs().max())
+    return moved, st.flat.master[: st.flat.used].clone().numpy(), st.version, out["steps"], max(st.staleness_log or [0])
+
+
+@pytest.mark.parametrize("placement,world", [("colocated", 3), ("dedicated", 3)])
+def test_async_ps_applies_every_gradient_and_replicas_end_equal(placement, world):
+    steps = 4
+    res = _run(_async_body, world, placement, steps)
+    n_workers = world if placement == "colocated" else world - 1
+    for moved, _, _, _, _ in res:
+        assert moved > 0
+    assert all((res[0][1] == r[1]).all() for r in res)        # finalize broadcasts the servers' shards
+    servers = res if placement == "colocated" else res[:1]
+    for _, _, version, _, max_stale in servers:
+        assert version == n_workers * steps                      # one apply per (worker, step)
+        assert max_stale <= n_workers * 2

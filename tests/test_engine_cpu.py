@@ -1,0 +1,210 @@
+"""CPU unit tests: flat arenas, bucket planner, optimizer formulas, Keras weight format, dataset pipeline."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from distributed_tensorflow_amd.api import keras_weights as kw  # noqa: E402
+from distributed_tensorflow_amd.api.layers import BatchNormalization, Conv2D, Dense, Flatten  # noqa: E402
+from distributed_tensorflow_amd.api.model import Sequential, as_model  # noqa: E402
+from distributed_tensorflow_amd.data.dataset import Dataset  # noqa: E402
+from distributed_tensorflow_amd.engine.flat import ALIGN, BucketPlanner, FlatParams  # noqa: E402
+from distributed_tensorflow_amd.engine.optimizer import SGD, Adam, FlatOptimizer  # noqa: E402
+from distributed_tensorflow_amd.engine.replica import Replica, TrainConfig  # noqa: E402
+from distributed_tensorflow_amd.models.mlp import mnist_cnn, reference_mlp  # noqa: E402
+
+
+def test_reference_mlp_has_the_reference_parameter_count():
+    m = reference_mlp()
+    assert m.count_params() == 407050            # 784*512 + 512 + 512*10 + 10
+    ws = m.get_weights()
+    assert [w.shape for w in ws] == [(784, 512), (512,), (512, 10), (10,)]   # Keras kernel layout (in, out)
+    p = m(torch.rand(5, 28, 28, 1))
+    assert p.shape == (5, 10) and torch.allclose(p.sum(1), torch.ones(5), atol=1e-5)
+
+
+def test_flat_params_views_and_reverse_order():
+    m = reference_mlp()
+    before = [p.detach().clone() for p in m.parameters()]
+    f = FlatParams.from_module(m, shard_ways=4)
+    assert f.total % (ALIGN * 4) == 0
+    for p, b in zip(m.parameters(), before):
+        assert torch.equal(p.detach(), b)
+    names = [s.name for s in f.slots]
+    assert names == list(reversed([n for n, _ in m.named_parameters()]))   # last layer first
+    # parameters are views: writing the arena changes the module
+    f.master.zero_()
+    assert all(float(p.detach().abs().sum()) == 0 for p in m.parameters())
+
+
+def test_flat_params_keep_channels_last_weights():
+    m = mnist_cnn()
+    conv_w = m.layers[0].weight
+    assert conv_w.is_contiguous(memory_format=torch.channels_last)
+    ref = conv_w.detach().clone()
+    f = FlatParams.from_module(m)
+    assert m.layers[0].weight.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(m.layers[0].weight.detach(), ref)
+    assert f.by_name["layers.0.weight"].stride == tuple(ref.stride())
+
+
+def test_bf16_params_get_master_and_shadow():
+    m = reference_mlp()
+    rep = Replica(m, "cpu", TrainConfig(param_dtype=torch.bfloat16))
+    f = rep.flat
+    assert f.shadow is not None and f.master.dtype == torch.float32
+    for s in f.slots:
+        assert s.param.dtype == torch.bfloat16
+        assert s.param.data_ptr() == f.shadow[s.offset:].data_ptr()
+    opt = FlatOptimizer(f, SGD(learning_rate=0.5))
+    f.grad.fill_(1.0)
+    m0 = f.master.clone()
+    opt.step()
+    assert torch.allclose(f.master, m0 - 0.5)
+    assert torch.equal(f.shadow, f.master.to(torch.bfloat16))   # compute copy refreshed in the same pass
+
+
+@pytest.mark.parametrize("ways", [1, 2, 8])
+def test_bucket_planner_partitions_the_arena(ways):
+    m = mnist_cnn()
+    f = FlatParams.from_module(m, shard_ways=ways)
+    pl = BucketPlanner(f, cap_bytes=200_000, first_cap_bytes=20_000)
+    assert pl.buckets[0].start == 0 and pl.buckets[-1].end == f.total
+    for a, b in zip(pl.buckets, pl.buckets[1:]):
+        assert a.end == b.start
+    assert sum(len(b.slots) for b in pl.buckets) == len(f.slots)
+    for b in pl.buckets:
+        assert b.numel % (ALIGN * ways) == 0
+        shards = [pl.shard_range(b, r) for r in range(ways)]
+        assert shards[0][0] == b.start and shards[-1][1] == b.end
+        assert all(e - s == b.numel // ways for s, e in shards)
+    assert len(pl.buckets) > 2
+
+
+def test_adam_keras_formula_matches_handwritten():
+    torch.manual_seed(0)
+    m = reference_mlp()
+    f = FlatParams.from_module(m)
+    opt = FlatOptimizer(f, Adam())
+    p0 = f.master.clone()
+    g = torch.randn_like(f.grad)
+    mm = torch.zeros_like(g); vv = torch.zeros_like(g); p = p0.clone()
+    for t in range(1, 4):
+        f.grad.copy_(g)
+        opt.step()
+        mm = 0.9 * mm + 0.1 * g
+        vv = 0.999 * vv + 0.001 * g * g
+        lr_t = 1e-3 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+        p = p - lr_t * mm / (vv.sqrt() + 1e-7)     # Keras: epsilon outside the bias-corrected sqrt
+    assert torch.allclose(f.master, p, atol=1e-6)
+
+
+def test_torch_adam_and_sgd_formulas_match_torch_optim():
+    torch.manual_seed(1)
+    for spec, ref_cls, kw_ in [(Adam(formula="torch", epsilon=1e-8), torch.optim.Adam, dict(lr=1e-3)),
+                               (SGD(learning_rate=0.1, momentum=0.9, formula="torch", weight_decay=1e-3), torch.optim.SGD,
+                                dict(lr=0.1, momentum=0.9, weight_decay=1e-3))]:
+        m = reference_mlp()
+        f = FlatParams.from_module(m)
+        ref_p = torch.nn.Parameter(f.master.clone())
+        ref = ref_cls([ref_p], **kw_)
+        opt = FlatOptimizer(f, spec)
+        for _ in range(3):
+            g = torch.randn_like(f.grad)
+            f.grad.copy_(g); ref_p.grad = g.clone()
+            opt.step(); ref.step()
+        assert torch.allclose(f.master, ref_p.detach(), atol=2e-6)
+
+
+def test_keras_weight_layouts_and_roundtrip(tmp_path):
+    m = Sequential([Conv2D(4, 3, input_shape=(8, 8, 2), padding="same"), BatchNormalization(), Flatten(), Dense(5)])
+    ws = m.get_weights()
+    assert [w.shape for w in ws] == [(3, 3, 2, 4), (4,), (4,), (4,), (4,), (4,), (256, 5), (5,)]
+    # HWIO <-> OIHW: kernel[h, w, i, o] == weight[o, i, h, w]
+    tw = m.layers[0].weight.detach().numpy()
+    assert ws[0][1, 2, 1, 3] == tw[3, 1, 1, 2]
+    # Dense kernel is (in, out)
+    assert ws[6][7, 2] == m.layers[3].weight.detach().numpy()[2, 7]
+    new = [np.random.default_rng(i).normal(size=w.shape).astype(np.float32) for i, w in enumerate(ws)]
+    new[5] = np.abs(new[5]) + 0.5     # moving_variance must be positive
+    m.set_weights(new)
+    for a, b in zip(m.get_weights(), new):
+        assert np.array_equal(a, b)
+    path = str(tmp_path / "w.npz")
+    m.save_weights(path)
+    m2 = Sequential([Conv2D(4, 3, input_shape=(8, 8, 2), padding="same"), BatchNormalization(), Flatten(), Dense(5)])
+    m2.load_weights(path)
+    x = torch.rand(3, 8, 8, 2)
+    m.eval(); m2.eval()
+    assert torch.allclose(m(x), m2(x), atol=1e-6)
+    with pytest.raises(ValueError):
+        m.set_weights(new[:-1])
+
+
+def test_keras_weights_of_plain_torch_modules():
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Flatten(), torch.nn.Linear(8, 2))
+    ws = kw.get_weights(net)
+    assert [w.shape for w in ws] == [(3, 3, 3, 8), (8,), (8,), (8,), (8,), (8,), (8, 2), (2,)]
+    kw.set_weights(net, ws)
+    wrapped = as_model(net)
+    assert len(wrapped.get_weights()) == len(ws) and len(wrapped.trainable_variables) == 6
+
+
+def test_flatten_uses_nhwc_order_like_keras():
+    m = Sequential([Conv2D(2, 1, input_shape=(2, 2, 1), use_bias=False), Flatten()])
+    with torch.no_grad():
+        m.layers[0].weight.copy_(torch.tensor([1.0, 10.0]).view(2, 1, 1, 1))
+    x = torch.arange(4.0).view(1, 2, 2, 1)
+    out = m(x)[0].tolist()
+    assert out == [0.0, 0.0, 1.0, 10.0, 2.0, 20.0, 3.0, 30.0]   # (h, w, c) fastest-last
+
+
+def test_dataset_shard_batch_shuffle_semantics():
+    x = np.arange(20, dtype=np.float32).reshape(20, 1)
+    y = np.arange(20, dtype=np.int32)
+    ds = Dataset.from_tensor_slices((x, y)).shard(2, 1).batch(3).shuffle(100, seed=7)
+    batches = [b for b in ds]
+    assert len(batches) == 4 and ds.num_batches() == 4
+    rows = sorted(int(v) for _, yy in batches for v in yy)
+    assert rows == list(range(1, 20, 2))                      # every 2nd element starting at 1
+    # shuffle after batch permutes batches, never examples inside a batch (reference initializer.py:44-45)
+    for _, yy in batches:
+        v = yy.tolist()
+        assert v == sorted(v) and all(b - a == 2 for a, b in zip(v, v[1:]))
+    with pytest.raises(ValueError):
+        Dataset.from_tensor_slices((x, y)).batch(2).shard(2, 0)
+    # a new epoch gives a new batch order with the same content
+    again = [yy.tolist() for _, yy in ds]
+    assert sorted(map(tuple, again)) == sorted(tuple(yy.tolist()) for _, yy in batches)
+
+
+def test_replica_sum_vs_mean_loss_gradients():
+    torch.manual_seed(0)
+    x = torch.rand(8, 28, 28, 1); y = torch.randint(0, 10, (8,), dtype=torch.int32)
+    grads = {}
+    for red in ("sum", "mean"):
+        torch.manual_seed(0)
+        rep = Replica(reference_mlp(dropout=0.0), "cpu", TrainConfig(loss_reduction=red))
+        rep.forward_backward(x, y)
+        rep.finish_backward()
+        grads[red] = rep.flat.grad.clone()
+    assert torch.allclose(grads["sum"], grads["mean"] * 8, rtol=1e-4, atol=1e-6)
+
+
+def test_reference_loss_on_clipped_probabilities():
+    """probs_clip_eps reproduces sparse_categorical_crossentropy applied to softmax outputs."""
+    from distributed_tensorflow_amd.ops.softmax_ce import softmax_cross_entropy
+    torch.manual_seed(0)
+    logits = torch.randn(6, 10) * 30          # saturating
+    y = torch.randint(0, 10, (6,))
+    exact = softmax_cross_entropy(logits, y)
+    clipped = softmax_cross_entropy(logits, y, probs_clip_eps=1e-7)
+    assert float(clipped.max()) <= -np.log(1e-7) + 1e-3      # bounded by -log(eps)
+    assert float(exact.max()) > float(clipped.max())
+    small = torch.randn(6, 10)
+    assert torch.allclose(softmax_cross_entropy(small, y), softmax_cross_entropy(small, y, probs_clip_eps=1e-7), atol=1e-5)
