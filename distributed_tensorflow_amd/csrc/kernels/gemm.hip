@@ -60,7 +60,22 @@ struct GemmArgs {
   int act;               // 0 none, 1 relu, 2 gelu(erf)
   int out_fp32;
   int tiles_m, tiles_n;
+  // batched GEMM: blockIdx.z = b1 * nb2 + b2; operand offsets b1 * s?1 + b2 * s?2 (elements)
+  int nb2;
+  long long sA1, sA2, sB1, sB2, sC1, sC2;
+  // pixel map of a strided 1x1 convolution: logical row r = (n, oh, ow) of the OUTPUT resolution
+  // addresses memory row (n*H + oh*S)*W + ow*S. map_mask bit 0: A's pixel index, bit 1: B's pixel
+  // index, bit 2: C's rows (the caller zero-fills C first).
+  int map_mask;
+  int mOW, mOH, mW, mH, mS;
 };
+
+__device__ __forceinline__ long long map_row(const GemmArgs& g, int r) {
+  const int hw = g.mOH * g.mOW;
+  const int n = r / hw, rem = r - n * hw;
+  const int oh = rem / g.mOW, ow = rem - oh * g.mOW;
+  return ((long long)n * g.mH + (long long)oh * g.mS) * g.mW + (long long)ow * g.mS;
+}
 
 __device__ __forceinline__ int swz_off(int row, int chunk) {
   return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -68,15 +83,18 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {
 
 // ---- staging: global -> registers -------------------------------------------------
 // k-contiguous operand X[row][k]: thread handles chunk ids tid + 256*i: row = id >> 3, chunk = id & 7.
-__device__ __forceinline__ void stage_load_kmajor(const unsigned short* __restrict__ X, long long ld, int rows,
-                                                  int row0, int k0, int kend, u32x4 (&r)[4]) {
+__device__ __forceinline__ void stage_load_kmajor(const GemmArgs& g, bool mapped, const unsigned short* __restrict__ X,
+                                                  long long ld, int rows, int row0, int k0, int kend, u32x4 (&r)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int id = threadIdx.x + kThreads * i;
     const int row = row0 + (id >> 3);
     const int k = k0 + ((id & 7) << 3);
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < rows && k < kend) v = *reinterpret_cast<const u32x4*>(X + (long long)row * ld + k);
+    if (row < rows && k < kend) {
+      const long long mr = mapped ? map_row(g, row) : (long long)row;
+      v = *reinterpret_cast<const u32x4*>(X + mr * ld + k);
+    }
     r[i] = v;
   }
 }
@@ -91,15 +109,18 @@ __device__ __forceinline__ void stage_store_kmajor(char* lds, const u32x4 (&r)[4
 
 // row-contiguous operand X[k][row]: thread handles row-chunk rc = tid & 15 (rows rc*8..+7) and the
 // four k-rows kg*4 .. kg*4+3 with kg = tid >> 4.
-__device__ __forceinline__ void stage_load_rmajor(const unsigned short* __restrict__ X, long long ld, int rows,
-                                                  int row0, int k0, int kend, u32x4 (&r)[4]) {
+__device__ __forceinline__ void stage_load_rmajor(const GemmArgs& g, bool mapped, const unsigned short* __restrict__ X,
+                                                  long long ld, int rows, int row0, int k0, int kend, u32x4 (&r)[4]) {
   const int rc = threadIdx.x & 15, kg = threadIdx.x >> 4;
   const int row = row0 + (rc << 3);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int k = k0 + kg * 4 + i;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < rows && k < kend) v = *reinterpret_cast<const u32x4*>(X + (long long)k * ld + row);
+    if (row < rows && k < kend) {
+      const long long mk = mapped ? map_row(g, k) : (long long)k;   // the pixel index is the contraction index here
+      v = *reinterpret_cast<const u32x4*>(X + mk * ld + row);
+    }
     r[i] = v;
   }
 }
@@ -121,10 +142,10 @@ __device__ __forceinline__ void stage_store_rmajor(char* lds, const u32x4 (&r)[4
 }
 
 template <int T>
-__device__ __forceinline__ void stage_load(const unsigned short* X, long long ld, int rows, int row0, int k0, int kend,
-                                           u32x4 (&r)[4]) {
-  if (T == 0) stage_load_kmajor(X, ld, rows, row0, k0, kend, r);
-  else stage_load_rmajor(X, ld, rows, row0, k0, kend, r);
+__device__ __forceinline__ void stage_load(const GemmArgs& g, bool mapped, const unsigned short* X, long long ld, int rows,
+                                           int row0, int k0, int kend, u32x4 (&r)[4]) {
+  if (T == 0) stage_load_kmajor(g, mapped, X, ld, rows, row0, k0, kend, r);
+  else stage_load_rmajor(g, mapped, X, ld, rows, row0, k0, kend, r);
 }
 template <int T>
 __device__ __forceinline__ void stage_store(char* lds, const u32x4 (&r)[4]) {
@@ -146,6 +167,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int split = blockIdx.y;
+  const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z - b1 * g.nb2;
+  const unsigned short* Ap = g.A + b1 * g.sA1 + b2 * g.sA2;
+  const unsigned short* Bp = g.B + b1 * g.sB1 + b2 * g.sB2;
+  const long long c_off = b1 * g.sC1 + b2 * g.sC2;
+  const bool mapA = g.map_mask & 1, mapB = g.map_mask & 2, mapC = g.map_mask & 4;
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nt = (kend - kbeg + BK - 1) / BK;
@@ -162,8 +188,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
 
   u32x4 ra[4], rb[4];
   if (nt > 0) {
-    stage_load<A_T>(g.A, g.lda, g.M, m0, kbeg, kend, ra);
-    stage_load<B_T>(g.B, g.ldb, g.N, n0, kbeg, kend, rb);
+    stage_load<A_T>(g, mapA, Ap, g.lda, g.M, m0, kbeg, kend, ra);
+    stage_load<B_T>(g, mapB, Bp, g.ldb, g.N, n0, kbeg, kend, rb);
     stage_store<A_T>(smem, ra);
     stage_store<B_T>(smem + kTileBytes, rb);
   }
@@ -174,8 +200,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     const bool more = (t + 1) < nt;
     if (more) {
       const int k0 = kbeg + (t + 1) * BK;
-      stage_load<A_T>(g.A, g.lda, g.M, m0, k0, kend, ra);
-      stage_load<B_T>(g.B, g.ldb, g.N, n0, k0, kend, rb);
+      stage_load<A_T>(g, mapA, Ap, g.lda, g.M, m0, k0, kend, ra);
+      stage_load<B_T>(g, mapB, Bp, g.ldb, g.N, n0, k0, kend, rb);
     }
     const char* la = smem + cur * 2 * kTileBytes;
     const char* lb = la + kTileBytes;
@@ -253,15 +279,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   }
 
   if (g.out_fp32) {
-    float* C = reinterpret_cast<float*>(g.C);
+    float* C = reinterpret_cast<float*>(g.C) + c_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = wm0 + i * 16 + fr;
       if (m >= g.M) continue;
+      const long long mr = mapC ? map_row(g, m) : (long long)m;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = wn0 + j * 16 + fq * 4;
-        if (n < g.N) *reinterpret_cast<f32x4*>(C + (long long)m * g.ldc + n) = acc[i][j];
+        if (n < g.N) *reinterpret_cast<f32x4*>(C + mr * g.ldc + n) = acc[i][j];
       }
     }
     return;
@@ -283,14 +310,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
   }
   __syncthreads();
-  unsigned short* C = reinterpret_cast<unsigned short*>(g.C);
+  unsigned short* C = reinterpret_cast<unsigned short*>(g.C) + c_off;
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int id = lane + 64 * p;
     const int row = id >> 3, chunk = id & 7;
     const int m = wm0 + row, n = wn0 + chunk * 8;
     const u32x4 v = *reinterpret_cast<const u32x4*>(stage + swz_off(row, chunk));
-    if (m < g.M && n < g.N) *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + n) = v;
+    if (m < g.M && n < g.N) {
+      const long long mr = mapC ? map_row(g, m) : (long long)m;
+      *reinterpret_cast<u32x4*>(C + mr * g.ldc + n) = v;
+    }
   }
 }
 
@@ -330,10 +360,16 @@ __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const float* __re
   }
 }
 
-// layout: 0 = NT, 1 = NN, 2 = TN (see the header comment). workspace: fp32, >= splits*M*N floats when splits > 1.
-DTF_API int dtf_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
-                          long long lda, long long ldb, long long ldc, int bias_dtype, int act, int out_fp32,
-                          int splits, void* workspace, hipStream_t stream) {
+// Extra, optional parameters of a launch (zero-initialise for a plain GEMM).
+struct GemmExtra {
+  int nb1, nb2;                      // batch = nb1 * nb2 (0 or 1 = not batched)
+  long long sA1, sA2, sB1, sB2, sC1, sC2;
+  int map_mask, mOW, mOH, mW, mH, mS;
+};
+
+static int gemm_launch(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                       long long lda, long long ldb, long long ldc, int bias_dtype, int act, int out_fp32,
+                       int splits, void* workspace, const GemmExtra* ex, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (splits < 1) splits = 1;
   GemmArgs g;
@@ -341,12 +377,24 @@ DTF_API int dtf_gemm_bf16(int layout, const void* A, const void* B, void* C, con
   g.bias = bias; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.bias_dtype = bias_dtype; g.act = act; g.out_fp32 = out_fp32;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  int batch = 1;
+  g.nb2 = 1; g.sA1 = g.sA2 = g.sB1 = g.sB2 = g.sC1 = g.sC2 = 0;
+  g.map_mask = 0; g.mOW = g.mOH = g.mW = g.mH = g.mS = 1;
+  if (ex) {
+    const int nb1 = ex->nb1 > 0 ? ex->nb1 : 1;
+    g.nb2 = ex->nb2 > 0 ? ex->nb2 : 1;
+    batch = nb1 * g.nb2;
+    g.sA1 = ex->sA1; g.sA2 = ex->sA2; g.sB1 = ex->sB1; g.sB2 = ex->sB2; g.sC1 = ex->sC1; g.sC2 = ex->sC2;
+    g.map_mask = ex->map_mask;
+    if (g.map_mask) { g.mOW = ex->mOW; g.mOH = ex->mOH; g.mW = ex->mW; g.mH = ex->mH; g.mS = ex->mS; }
+  }
+  if (batch > 1 || (g.map_mask & 4)) splits = 1;   // split-K slabs are neither batched nor row-mapped
   int kps = ((K + splits - 1) / splits + BK - 1) / BK * BK;
   splits = (K + kps - 1) / kps;
   g.k_per_split = kps; g.splits = splits;
   g.C = splits > 1 ? workspace : C;
   if (splits > 1 && !workspace) return -3;
-  const dim3 grid(g.tiles_m * g.tiles_n, splits);
+  const dim3 grid(g.tiles_m * g.tiles_n, splits, batch);
   const size_t lds = 4 * kTileBytes;
   switch (layout) {
     case 0: hipLaunchKernelGGL((gemm_bf16_kernel<0, 0>), grid, dim3(kThreads), lds, stream, g); break;
@@ -360,4 +408,20 @@ DTF_API int dtf_gemm_bf16(int layout, const void* A, const void* B, void* C, con
                        (const float*)workspace, C, bias, bias_dtype, act, out_fp32, splits, M, N, ldc);
   }
   return (int)hipGetLastError();
+}
+
+// layout: 0 = NT, 1 = NN, 2 = TN (see the header comment). workspace: fp32, >= splits*M*N floats when splits > 1.
+DTF_API int dtf_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                          long long lda, long long ldb, long long ldc, int bias_dtype, int act, int out_fp32,
+                          int splits, void* workspace, hipStream_t stream) {
+  return gemm_launch(layout, A, B, C, bias, M, N, K, lda, ldb, ldc, bias_dtype, act, out_fp32, splits, workspace,
+                     nullptr, stream);
+}
+
+// Batched and/or pixel-mapped variant; `ex` points to a GemmExtra.
+DTF_API int dtf_gemm_bf16_ex(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                             long long lda, long long ldb, long long ldc, int bias_dtype, int act, int out_fp32,
+                             int splits, void* workspace, const void* ex, hipStream_t stream) {
+  return gemm_launch(layout, A, B, C, bias, M, N, K, lda, ldb, ldc, bias_dtype, act, out_fp32, splits, workspace,
+                     (const GemmExtra*)ex, stream);
 }

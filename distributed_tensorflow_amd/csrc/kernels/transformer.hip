@@ -1,0 +1,351 @@
+// Row-wise kernels of the transformer (BERT) configuration for gfx950:
+//   * LayerNorm forward/backward with the residual add fused in,
+//   * attention softmax forward/backward (scale and key-padding bias fused),
+// The reference has no attention model (reference initializer.py:12-21 is an MLP); these are
+// the LayerNorm / attention ops of the "BERT-base MLM" benchmark configuration. The attention
+// products themselves (QK^T, PV and their gradients) run on the batched MFMA GEMM.
+//
+// Common structure: one 64-lane wave owns a row; a lane holds up to CH 16-byte chunks
+// (8 bf16 each) of it in registers, so a row is read from memory exactly once per pass.
+#include "dtf_common.h"
+
+using namespace dtf;
+
+__device__ __forceinline__ void t_ld8(const unsigned short* p, float (&o)[8]) {
+  u16x8 a = *reinterpret_cast<const u16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(a[i]);
+}
+__device__ __forceinline__ void t_st8(unsigned short* p, const float (&o)[8]) {
+  u16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = f32_to_bf16(o[i]);
+  *reinterpret_cast<u16x8*>(p) = a;
+}
+template <typename P>
+__device__ __forceinline__ void t_ldp(const P* p, float (&o)[8]);
+template <>
+__device__ __forceinline__ void t_ldp<float>(const float* p, float (&o)[8]) {
+  f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+template <>
+__device__ __forceinline__ void t_ldp<unsigned short>(const unsigned short* p, float (&o)[8]) { t_ld8(p, o); }
+
+// ------------------------------------------------------------------------------ LayerNorm
+// y = LN(x (+ res)) * gamma + beta ; optionally writes s = x + res (the new residual stream).
+// stats[row] = {mean, rstd}. H % 8 == 0, H <= 64 * 8 * CH.
+template <int CH, typename P>
+__global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const unsigned short* __restrict__ x,
+                                                        const unsigned short* __restrict__ res,
+                                                        const P* __restrict__ gamma, const P* __restrict__ beta,
+                                                        unsigned short* __restrict__ y,
+                                                        unsigned short* __restrict__ sum_out,
+                                                        float* __restrict__ stats, long long rows, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = H >> 3;
+  float v[CH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      t_ld8(x + row * H + ch * 8, v[c]);
+      if (res) {
+        float r[8];
+        t_ld8(res + row * H + ch * 8, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[c][k] += r[k];
+      }
+      if (sum_out) {
+        t_st8(sum_out + row * H + ch * 8, v[c]);
+        // normalise what later layers will read back: the bf16-rounded sum
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[c][k] = bf16_to_f32(f32_to_bf16(v[c][k]));
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[c][k];
+    }
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (lane + 64 * c < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = v[c][k] - mean; q = fmaf(d, d, q); }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+  if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      float g[8], b[8], o[8];
+      t_ldp<P>(gamma + ch * 8, g); t_ldp<P>(beta + ch * 8, b);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = fmaf((v[c][k] - mean) * rstd, g[k], b[k]);
+      t_st8(y + row * H + ch * 8, o);
+    }
+  }
+}
+
+// dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) (+ dres_in when given);
+// per-block partial sums of dgamma = sum g*xhat and dbeta = sum g go to part[block][2][H].
+template <int CH, typename P>
+__global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const unsigned short* __restrict__ x,
+                                                        const unsigned short* __restrict__ dy,
+                                                        const unsigned short* __restrict__ dres_in,
+                                                        const P* __restrict__ gamma, const float* __restrict__ stats,
+                                                        unsigned short* __restrict__ dx, float* __restrict__ part,
+                                                        long long rows, int H, int rows_per_block) {
+  __shared__ float red[2][4][64 * CH * 8 / 4 + 1];  // reduced in four rounds to bound LDS (see below)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  float dg[CH][8], db[CH][8], gam[CH][8];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dg[c][k] = 0.f; db[c][k] = 0.f; gam[c][k] = 0.f; }
+    if (lane + 64 * c < nch) t_ldp<P>(gamma + (lane + 64 * c) * 8, gam[c]);
+  }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(rows, r0 + rows_per_block);
+  for (long long row = r0 + wid; row < r1; row += kBlock / 64) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float xh[CH][8], g[CH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        t_ld8(x + row * H + ch * 8, xh[c]);
+        t_ld8(dy + row * H + ch * 8, g[c]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          xh[c][k] = (xh[c][k] - mean) * rstd;
+          dg[c][k] = fmaf(g[c][k], xh[c][k], dg[c][k]);
+          db[c][k] += g[c][k];
+          g[c][k] *= gam[c][k];
+          s1 += g[c][k];
+          s2 = fmaf(g[c][k], xh[c][k], s2);
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = rstd * (g[c][k] - s1 - xh[c][k] * s2);
+        if (dres_in) {
+          float r[8];
+          t_ld8(dres_in + row * H + ch * 8, r);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] += r[k];
+        }
+        t_st8(dx + row * H + ch * 8, o);
+      }
+    }
+  }
+  // combine the 4 waves' partials: wave w adds into wave 0's registers through LDS, 2 values at a time
+  float* pg = part + ((long long)blockIdx.x * 2) * H;
+  float* pb = pg + H;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      __syncthreads();
+      red[0][wid][lane * 2] = dg[c][k]; red[0][wid][lane * 2 + 1] = dg[c][k + 1];
+      red[1][wid][lane * 2] = db[c][k]; red[1][wid][lane * 2 + 1] = db[c][k + 1];
+      __syncthreads();
+      if (wid == 0 && lane + 64 * c < nch) {
+        const int col = (lane + 64 * c) * 8 + k;
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a0 += red[0][w][lane * 2]; a1 += red[0][w][lane * 2 + 1];
+          b0 += red[1][w][lane * 2]; b1 += red[1][w][lane * 2 + 1];
+        }
+        pg[col] = a0; pg[col + 1] = a1; pb[col] = b0; pb[col + 1] = b1;
+      }
+    }
+  }
+}
+
+// out[2][H]: column sums of part[n_part][2][H]; one thread per column pair index.
+__global__ __launch_bounds__(kBlock) void ln_bwd_finalize_kernel(const float* __restrict__ part, int n_part, int H,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * H) return;
+  float s = 0.f;
+  for (int p = 0; p < n_part; ++p) s += part[(long long)p * 2 * H + c];
+  if (c < H) dgamma[c] = s; else dbeta[c - H] = s;
+}
+
+// ------------------------------------------------------------------------------ softmax
+// In-place capable. Row r of the [rows, L] matrix belongs to batch b = r / rows_per_batch.
+// p = softmax(scale * s + bias[b, :]) ;  bias may be null (fp32, 0 / -inf style additive mask).
+template <int CH>
+__global__ __launch_bounds__(kBlock) void softmax_fwd_kernel(const unsigned short* __restrict__ s,
+                                                             unsigned short* __restrict__ p,
+                                                             const float* __restrict__ bias, long long rows, int L,
+                                                             long long rows_per_batch, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = L >> 3;
+  const float* brow = bias ? bias + (row / rows_per_batch) * L : nullptr;
+  float v[CH][8];
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      t_ld8(s + row * L + ch * 8, v[c]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[c][k] *= scale;
+        if (brow) v[c][k] += brow[ch * 8 + k];
+        m = fmaxf(m, v[c][k]);
+      }
+    }
+  }
+  m = wave_max(m);
+  if (m == -INFINITY) m = 0.f;  // fully masked row -> zeros, not NaN
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (lane + 64 * c < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { v[c][k] = __expf(v[c][k] - m); sum += v[c][k]; }
+    }
+  }
+  sum = wave_sum(sum);
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[c][k] *= inv;
+      t_st8(p + row * L + ch * 8, v[c]);
+    }
+  }
+}
+
+// ds = scale * p * (dp - sum(p * dp)); in-place capable on dp.
+template <int CH>
+__global__ __launch_bounds__(kBlock) void softmax_bwd_kernel(const unsigned short* __restrict__ p,
+                                                             const unsigned short* __restrict__ dp,
+                                                             unsigned short* __restrict__ ds, long long rows, int L,
+                                                             float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = L >> 3;
+  float pv[CH][8], g[CH][8];
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      t_ld8(p + row * L + ch * 8, pv[c]);
+      t_ld8(dp + row * L + ch * 8, g[c]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dot = fmaf(pv[c][k], g[c][k], dot);
+    }
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[c][k] = scale * pv[c][k] * (g[c][k] - dot);
+      t_st8(ds + row * L + ch * 8, g[c]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ C ABI
+static inline int ch_for(int n) { return n <= 512 ? 1 : n <= 1024 ? 2 : n <= 2048 ? 4 : n <= 4096 ? 8 : 0; }
+
+DTF_API int dtf_ln_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* y, void* sum_out,
+                       float* stats, long long rows, int H, float eps, int param_dtype, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  const int ch = ch_for(H);
+  if (H % 8 || ch == 0) return -1;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define LN(CHN, P)                                                                                           \
+  hipLaunchKernelGGL((ln_fwd_kernel<CHN, P>), grid, dim3(kBlock), 0, stream, (const unsigned short*)x,      \
+                     (const unsigned short*)res, (const P*)gamma, (const P*)beta, (unsigned short*)y,       \
+                     (unsigned short*)sum_out, stats, rows, H, eps)
+#define LN_D(CHN) do { if (param_dtype == 0) LN(CHN, float); else LN(CHN, unsigned short); } while (0)
+  switch (ch) { case 1: LN_D(1); break; case 2: LN_D(2); break; case 4: LN_D(4); break; default: LN_D(8); }
+#undef LN_D
+#undef LN
+  return (int)hipGetLastError();
+}
+
+DTF_API int dtf_ln_bwd_num_partials(long long rows) {
+  long long nb = (rows + 63) / 64;
+  if (nb > 512) nb = 512;
+  return (int)(nb < 1 ? 1 : nb);
+}
+
+// part: fp32 [n_partials * 2 * H]
+DTF_API int dtf_ln_bwd(const void* x, const void* dy, const void* dres_in, const void* gamma, const float* stats,
+                       void* dx, float* dgamma, float* dbeta, float* part, long long rows, int H, int param_dtype,
+                       hipStream_t stream) {
+  if (rows <= 0) return 0;
+  const int ch = ch_for(H);
+  if (H % 8 || ch == 0 || ch > 4) return -1;
+  const int nb = dtf_ln_bwd_num_partials(rows);
+  const int rpb = (int)((rows + nb - 1) / nb);
+#define LNB(CHN, P)                                                                                          \
+  hipLaunchKernelGGL((ln_bwd_kernel<CHN, P>), dim3(nb), dim3(kBlock), 0, stream, (const unsigned short*)x,  \
+                     (const unsigned short*)dy, (const unsigned short*)dres_in, (const P*)gamma, stats,     \
+                     (unsigned short*)dx, part, rows, H, rpb)
+#define LNB_D(CHN) do { if (param_dtype == 0) LNB(CHN, float); else LNB(CHN, unsigned short); } while (0)
+  switch (ch) { case 1: LNB_D(1); break; case 2: LNB_D(2); break; default: LNB_D(4); }
+#undef LNB_D
+#undef LNB
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * H + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, part, nb, H,
+                     dgamma, dbeta);
+  return (int)hipGetLastError();
+}
+
+DTF_API int dtf_softmax_fwd(const void* s, void* p, const float* bias, long long rows, int L, long long rows_per_batch,
+                            float scale, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  const int ch = ch_for(L);
+  if (L % 8 || ch == 0) return -1;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define SM(CHN)                                                                                               \
+  hipLaunchKernelGGL((softmax_fwd_kernel<CHN>), grid, dim3(kBlock), 0, stream, (const unsigned short*)s,     \
+                     (unsigned short*)p, bias, rows, L, rows_per_batch, scale)
+  switch (ch) { case 1: SM(1); break; case 2: SM(2); break; case 4: SM(4); break; default: SM(8); }
+#undef SM
+  return (int)hipGetLastError();
+}
+
+DTF_API int dtf_softmax_bwd(const void* p, const void* dp, void* ds, long long rows, int L, float scale,
+                            hipStream_t stream) {
+  if (rows <= 0) return 0;
+  const int ch = ch_for(L);
+  if (L % 8 || ch == 0) return -1;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define SMB(CHN)                                                                                              \
+  hipLaunchKernelGGL((softmax_bwd_kernel<CHN>), grid, dim3(kBlock), 0, stream, (const unsigned short*)p,     \
+                     (const unsigned short*)dp, (unsigned short*)ds, rows, L, scale)
+  switch (ch) { case 1: SMB(1); break; case 2: SMB(2); break; case 4: SMB(4); break; default: SMB(8); }
+#undef SMB
+  return (int)hipGetLastError();
+}

@@ -115,10 +115,12 @@ class Replica:
         correct = torch.zeros((), dtype=torch.int64, device=self.device)
         n = 0
         it = dataset.iterate(self.device) if hasattr(dataset, "iterate") else iter(dataset)
-        for i, (x, y) in enumerate(it):
+        for i, batch in enumerate(it):
             if max_batches is not None and i >= max_batches:
                 break
-            x, y = x.to(self.device), y.to(self.device)
+            x, y = (batch[0] if len(batch) == 2 else tuple(batch[:-1])), batch[-1]
+            x = tuple(t.to(self.device) for t in x) if isinstance(x, tuple) else x.to(self.device)
+            y = y.to(self.device)
             if self.model.supports_logits:
                 out = self.model(x, logits=True)
                 l, c = softmax_ce_eval(out, y if y.dtype in (torch.int32, torch.int64) else y.long())

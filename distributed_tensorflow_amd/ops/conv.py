@@ -35,31 +35,46 @@ def get_conv1x1_backend() -> str:
 
 
 class _Conv1x1Fn(torch.autograd.Function):
+    """1x1 convolution, stride s >= 1, as three GEMMs on the NHWC bytes. With a stride the GEMM
+    reads (forward, weight gradient) or writes (data gradient) only the strided pixels through the
+    kernel's row map, so no gathered copy of the activation is ever made."""
+
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, stride):
         N, C, H, W = x.shape
         K = w.shape[0]
-        x2 = x.permute(0, 2, 3, 1).reshape(N * H * W, C)          # view of the NHWC bytes
+        OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
         w2 = w.reshape(K, C)
-        y2 = _gemm.gemm_nt(x2, w2)
-        ctx.save_for_backward(x2, w2)
-        ctx.dims = (N, C, H, W, K)
-        ctx.w_shape, ctx.w_stride = w.shape, w.stride()
-        return y2.view(N, H, W, K).permute(0, 3, 1, 2)
+        y = torch.empty((N, OH, OW, K), dtype=x.dtype, device=x.device)
+        ex = _gemm.pixel_map(_gemm.MAP_A, (OH, OW), (H, W), stride) if stride != 1 else None
+        _gemm.gemm_raw(_gemm.NT, x, w2, y, N * OH * OW, K, C, C, C, K, extra=ex)
+        ctx.save_for_backward(x, w2)
+        ctx.dims = (N, C, H, W, K, OH, OW, stride)
+        return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
-        x2, w2 = ctx.saved_tensors
-        N, C, H, W, K = ctx.dims
-        g2 = gy.permute(0, 2, 3, 1).reshape(N * H * W, K)
-        if not g2.is_contiguous():
-            g2 = g2.contiguous()
+        x, w2 = ctx.saved_tensors
+        N, C, H, W, K, OH, OW, stride = ctx.dims
+        if not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.contiguous(memory_format=torch.channels_last)
+        M = N * OH * OW
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _gemm.gemm_nn(g2, w2).view(N, H, W, C).permute(0, 3, 1, 2)
+            if stride != 1:
+                gx = torch.zeros((N, H, W, C), dtype=x.dtype, device=x.device)
+                ex = _gemm.pixel_map(_gemm.MAP_C, (OH, OW), (H, W), stride)
+            else:
+                gx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+                ex = None
+            _gemm.gemm_raw(_gemm.NN, gy, w2, gx, M, C, K, K, C, C, extra=ex)
+            gx = gx.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            gw = _gemm.gemm_tn(g2, x2).view(K, 1, 1, C).permute(0, 3, 1, 2)   # [K, C, 1, 1], channels_last
-        return gx, gw
+            gw = torch.empty((K, C), dtype=w2.dtype, device=x.device)
+            ex = _gemm.pixel_map(_gemm.MAP_B, (OH, OW), (H, W), stride) if stride != 1 else None
+            _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, M, K, C, C, extra=ex)
+            gw = gw.view(K, 1, 1, C).permute(0, 3, 1, 2)   # [K, C, 1, 1], channels_last
+        return gx, gw, None
 
 
 def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -70,9 +85,7 @@ def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
 def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
     """Bias-free convolution of a channels_last activation with an ``[O, I, kh, kw]`` weight."""
     if w.shape[2] == 1 and w.shape[3] == 1 and padding == 0 and _backend == "gemm" and _gemm_ok(x, w):
-        if stride != 1:
-            x = x[:, :, ::stride, ::stride].contiguous(memory_format=torch.channels_last)
-        return _Conv1x1Fn.apply(x, w)
+        return _Conv1x1Fn.apply(x, w, stride)
     if x.dtype != w.dtype:
         x = x.to(w.dtype)
     return F.conv2d(x, w, None, stride, padding)

@@ -37,6 +37,39 @@ def supported(x: torch.Tensor, w: torch.Tensor) -> bool:
             and w.is_contiguous() and x.numel() > 0)
 
 
+class GemmExtra(ctypes.Structure):
+    """Mirror of the kernel's ``GemmExtra``: batch dims/strides and the strided-pixel row map."""
+    _fields_ = [("nb1", ctypes.c_int), ("nb2", ctypes.c_int),
+                ("sA1", ctypes.c_longlong), ("sA2", ctypes.c_longlong), ("sB1", ctypes.c_longlong),
+                ("sB2", ctypes.c_longlong), ("sC1", ctypes.c_longlong), ("sC2", ctypes.c_longlong),
+                ("map_mask", ctypes.c_int), ("mOW", ctypes.c_int), ("mOH", ctypes.c_int), ("mW", ctypes.c_int),
+                ("mH", ctypes.c_int), ("mS", ctypes.c_int)]
+
+
+MAP_A, MAP_B, MAP_C = 1, 2, 4
+
+
+def pixel_map(mask: int, out_hw: tuple[int, int], in_hw: tuple[int, int], stride: int) -> GemmExtra:
+    """Row map of a strided 1x1 convolution: GEMM row (n, oh, ow) <-> memory row (n, oh*stride, ow*stride)."""
+    ex = GemmExtra()
+    ex.nb1 = ex.nb2 = 1
+    ex.map_mask = mask
+    ex.mOH, ex.mOW = out_hw
+    ex.mH, ex.mW = in_hw
+    ex.mS = stride
+    return ex
+
+
+def batch_dims(nb1: int, nb2: int, sA, sB, sC) -> GemmExtra:
+    """Two-level batch: operand offsets ``b1 * s[0] + b2 * s[1]`` elements."""
+    ex = GemmExtra()
+    ex.nb1, ex.nb2 = nb1, nb2
+    ex.sA1, ex.sA2 = sA
+    ex.sB1, ex.sB2 = sB
+    ex.sC1, ex.sC2 = sC
+    return ex
+
+
 _workspaces: dict[tuple, torch.Tensor] = {}
 
 
@@ -57,12 +90,19 @@ def _pick_splits(M: int, N: int, K: int) -> int:
     return max(1, min(want, K // 256, 64))
 
 
-def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, splits, out=None):
+def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, splits, out=None, extra=None,
+            ldc=None):
     dev = A.device
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=dev)
-    if N % 8 or out.stride(1) != 1 or out.data_ptr() % 16:
+    if ldc is None:
+        ldc = out.stride(0)
+        if out.stride(1) != 1:
+            raise ValueError("gemm output must be row-major")
+    if N % 8 or ldc % 8 or out.data_ptr() % 16:
         raise ValueError("gemm output needs N % 8 == 0 and a 16-byte aligned row-major buffer")
+    if extra is not None and (extra.nb1 * extra.nb2 > 1 or extra.map_mask & MAP_C):
+        splits = 1
     if splits is None:
         splits = _pick_splits(M, N, K)
     ws = _workspace(dev, splits * M * N) if splits > 1 else None
@@ -71,11 +111,11 @@ def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, s
         if bias.numel() != N or not bias.is_contiguous():
             raise ValueError("bias must be a contiguous [N] vector")
         bias_dtype = _lib.dtype_code(bias.dtype)
-    rc = _lib.kernels().dtf_gemm_bf16(layout, _lib.ptr(A), _lib.ptr(B), _lib.ptr(out), _lib.ptr(bias), M, N, K,
-                                      ctypes.c_longlong(lda), ctypes.c_longlong(ldb),
-                                      ctypes.c_longlong(out.stride(0)), bias_dtype, _ACT[activation],
-                                      1 if out.dtype == torch.float32 else 0, splits, _lib.ptr(ws),
-                                      _lib.stream_ptr(dev))
+    rc = _lib.kernels().dtf_gemm_bf16_ex(layout, _lib.ptr(A), _lib.ptr(B), _lib.ptr(out), _lib.ptr(bias), M, N, K,
+                                         ctypes.c_longlong(lda), ctypes.c_longlong(ldb), ctypes.c_longlong(ldc),
+                                         bias_dtype, _ACT[activation], 1 if out.dtype == torch.float32 else 0,
+                                         splits, _lib.ptr(ws), ctypes.byref(extra) if extra is not None else None,
+                                         _lib.stream_ptr(dev))
     _lib.check(rc, "gemm_bf16")
     return out
 
@@ -103,6 +143,18 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=N
         raise ValueError("gemm_tn: operands must be 16-byte aligned bf16 [K,M] and [K,N]")
     return _launch(TN, a, b, a.shape[1], b.shape[1], a.shape[0], a.stride(0), b.stride(0), None, None, out_dtype,
                    splits, out)
+
+
+def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int,
+             ldb: int, ldc: int, extra: GemmExtra | None = None, bias=None, activation=None, splits=None):
+    """Unchecked launch on explicit dimensions and leading dimensions (batched attention products,
+    strided 1x1 convolutions). The caller guarantees 16-byte alignment of every row it addresses."""
+    for t in (A, B, out):
+        if t.data_ptr() % 16:
+            raise ValueError("gemm_raw: operands must be 16-byte aligned")
+    if lda % 8 or ldb % 8 or ldc % 8:
+        raise ValueError("gemm_raw: leading dimensions must be multiples of 8 elements")
+    return _launch(layout, A, B, M, N, K, lda, ldb, bias, activation, out.dtype, splits, out=out, extra=extra, ldc=ldc)
 
 
 def _ew(op: int, a: torch.Tensor, b: torch.Tensor | None) -> torch.Tensor:

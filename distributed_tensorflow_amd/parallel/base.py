@@ -39,6 +39,9 @@ class Strategy:
         self.metrics = metrics or MetricsLogger(None, rank=comm.rank)
         self.optimizer: FlatOptimizer | None = None
         self._side_stream = None
+        # row-sharded embedding tables are parameter-server state outside the dense arenas
+        from .sharded_embedding import ShardedEmbedding
+        self.sparse_modules = [m for m in self.replica.model.modules() if isinstance(m, ShardedEmbedding)]
 
     # ------------------------------------------------------------ lifecycle
     def broadcast_initial(self, src: int = 0) -> None:
@@ -54,6 +57,13 @@ class Strategy:
 
     def train_step(self, x, y) -> torch.Tensor:  # pragma: no cover - interface
         raise NotImplementedError
+
+    def apply_sparse(self) -> None:
+        """Parameter-server apply of the sparse (embedding) gradients pushed during backward."""
+        if self.sparse_modules:
+            scale = 1.0 / self.comm.world if self.cfg.loss_reduction == "mean" else 1.0
+            for m in self.sparse_modules:
+                m.apply(scale)
 
     def finalize(self) -> None:
         """Brings every replica to the final model (no-op for strategies whose replicas agree)."""
@@ -83,7 +93,8 @@ class Strategy:
         for ep in range(epochs):
             it = dataset.iterate(dev)
             for i in range(steps_per_epoch):
-                x, y = next(it)
+                batch = next(it)
+                x, y = (batch[0] if len(batch) == 2 else tuple(batch[:-1])), batch[-1]
                 if fault_hook is not None:
                     fault_hook(self.comm.rank, it_count)
                 ts = time.time()

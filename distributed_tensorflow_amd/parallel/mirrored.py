@@ -50,6 +50,7 @@ class MirroredStrategy(Strategy):
             if w is not None:
                 w.wait()
         self.optimizer.step()
+        self.apply_sparse()
         return loss
 
 

@@ -104,6 +104,7 @@ class SyncPSStrategy(Strategy):
                 self.comm.all_gather(f.master[b.start:b.end], f.master[a:e])
                 self.bytes_pulled += (b.numel - (e - a)) * 4
             f.refresh_shadow()
+        self.apply_sparse()
         return loss
 
 

@@ -279,3 +279,117 @@ def test_resnet_train_step_decreases_loss():
     losses = [float(st.train_step(x, y)) for _ in range(12)]
     assert all(l == l for l in losses)
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("rows,H", [(7, 768), (300, 128), (64, 1024), (33, 2048), (5, 40)])
+@pytest.mark.parametrize("pdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("use_res", [False, True])
+def test_layer_norm_matches_torch(rows, H, pdt, use_res):
+    from distributed_tensorflow_amd.ops.layernorm import layer_norm
+    torch.manual_seed(H)
+    x = torch.randn(rows, H, device=DEV).to(torch.bfloat16)
+    r = torch.randn(rows, H, device=DEV).to(torch.bfloat16)
+    g = (torch.rand(H, device=DEV) + 0.5).to(pdt); b = torch.randn(H, device=DEV).to(pdt)
+    x1, r1, g1, b1 = (t.clone().requires_grad_(True) for t in (x, r, g, b))
+    if use_res:
+        y, s = layer_norm(x1, g1, b1, 1e-5, residual=r1, return_sum=True)
+        dy, dsum = torch.randn_like(y), torch.randn_like(y)
+        (y.float() * dy.float()).sum().add((s.float() * dsum.float()).sum()).backward()
+    else:
+        y = layer_norm(x1, g1, b1, 1e-5)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+    xr, rr, gr, br = (t.float().clone().requires_grad_(True) for t in (x, r, g, b))
+    sr = (xr + rr) + ((xr + rr).to(torch.bfloat16).float() - (xr + rr)).detach() if use_res else xr
+    yr = torch.nn.functional.layer_norm(sr, (H,), gr, br, 1e-5)
+    if use_res:
+        ((yr * dy.float()).sum() + (sr * dsum.float()).sum()).backward()
+        torch.testing.assert_close(s.float(), sr.detach(), rtol=1e-2, atol=1e-2)
+    else:
+        yr.backward(dy.float())
+    torch.testing.assert_close(y.float(), yr.detach(), rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(x1.grad.float(), xr.grad, rtol=3e-2, atol=6e-2)
+    if use_res:
+        torch.testing.assert_close(r1.grad.float(), rr.grad, rtol=3e-2, atol=6e-2)
+    sc = max(1.0, float(gr.grad.abs().max()))
+    torch.testing.assert_close(g1.grad.float() / sc, gr.grad / sc, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(b1.grad.float() / sc, br.grad / sc, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("B,S,nh,hd", [(2, 128, 4, 64), (3, 512, 2, 64), (1, 64, 3, 32), (2, 72, 2, 64)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention_matches_reference(B, S, nh, hd, masked):
+    from distributed_tensorflow_amd.ops.attention import self_attention
+    torch.manual_seed(S + nh)
+    qkv = (torch.randn(B, S, 3, nh, hd, device=DEV) * 0.7).to(torch.bfloat16)
+    bias = None
+    if masked:
+        bias = torch.zeros(B, S, device=DEV)
+        bias[:, S - 9:] = float("-inf")
+    q1 = qkv.clone().requires_grad_(True)
+    out = self_attention(q1, bias)
+    do = torch.randn_like(out)
+    out.backward(do)
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = (qr[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2) / math.sqrt(hd)
+    if masked:
+        s = s + bias[:, None, None, :]
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3)
+    ref.backward(do.float())
+    torch.testing.assert_close(out.float(), ref.detach(), rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(q1.grad.float(), qr.grad, rtol=5e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_embedding_gather_scatter_and_sparse_path(dt):
+    from distributed_tensorflow_amd.ops import embedding as E
+    torch.manual_seed(5)
+    V, D, B, S = 1000, 64, 6, 16
+    table = torch.randn(V, D, device=DEV).to(dt).requires_grad_(True)
+    pos = torch.randn(32, D, device=DEV).to(dt).requires_grad_(True)
+    typ = torch.randn(2, D, device=DEV).to(dt).requires_grad_(True)
+    ids = torch.randint(0, V, (B, S), device=DEV)
+    ids[0, :4] = 7                                  # repeated ids exercise accumulation
+    tt = torch.randint(0, 2, (B, S), device=DEV)
+    out = E.embedding(table, ids, pos, typ, tt)
+    ref = table.detach().float()[ids] + pos.detach().float()[:S][None] + typ.detach().float()[tt]
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=2e-2)
+    g = torch.randn_like(out)
+    out.backward(g)
+    dref = torch.zeros(V, D, device=DEV).index_add_(0, ids.reshape(-1), g.float().reshape(-1, D))
+    torch.testing.assert_close(table.grad.float(), dref, rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(pos.grad.float()[:S], g.float().sum(0), rtol=2e-2, atol=5e-2)
+    assert float(pos.grad.float()[S:].abs().sum()) == 0
+    dtyp = torch.zeros(2, D, device=DEV).index_add_(0, tt.reshape(-1), g.float().reshape(-1, D))
+    torch.testing.assert_close(typ.grad.float(), dtyp, rtol=2e-2, atol=2e-1)
+    # sparse path: unique ids + segment sum == dense scatter-add restricted to the touched rows
+    uniq, perm, seg = E.unique_segments(ids)
+    gs = E.segment_sum(g.reshape(-1, D), perm, seg)
+    torch.testing.assert_close(gs, dref[uniq], rtol=1e-3, atol=1e-3)
+    # shard-local gather: ids outside the shard give zeros
+    half = E._gather(table.detach()[500:], ids, row_base=500)
+    exp = torch.where((ids >= 500)[..., None], table.detach().float()[ids], torch.zeros((), device=DEV)).reshape(-1, D)
+    torch.testing.assert_close(half.float(), exp, rtol=1e-2, atol=1e-2)
+    # sparse optimizer kernels vs the CPU formulas
+    for kind in (E.SGD, E.ADAGRAD, E.ADAM):
+        tab = torch.randn(V, D, device=DEV); m = torch.zeros_like(tab); v = torch.zeros_like(tab)
+        tc, mc, vc = tab.cpu().clone(), m.cpu().clone(), v.cpu().clone()
+        hyper = torch.tensor([0.1, 0.1, 0.001, 1e-7, 0.9, 0.999, 0.5, 0.0], device=DEV)
+        E.sparse_apply(tab, m, v, gs, uniq, hyper, kind)
+        E.sparse_apply(tc, mc, vc, gs.cpu(), uniq.cpu(), hyper.cpu(), kind)
+        torch.testing.assert_close(tab.cpu(), tc, rtol=1e-4, atol=1e-5)
+
+
+def test_bert_tiny_trains_on_gpu():
+    from distributed_tensorflow_amd.engine.optimizer import Adam, FlatOptimizer
+    from distributed_tensorflow_amd.engine.replica import Replica, TrainConfig
+    from distributed_tensorflow_amd.models.bert import bert_tiny, synthetic_mlm_batch
+    torch.manual_seed(0)
+    rep = Replica(bert_tiny(), DEV, TrainConfig(param_dtype=torch.bfloat16))
+    opt = FlatOptimizer(rep.flat, Adam(learning_rate=1e-3))
+    x, y = synthetic_mlm_batch(8, 64, 1024, DEV, n_pred=8)
+    losses = []
+    for _ in range(8):
+        losses.append(float(rep.forward_backward(x, y))); rep.finish_backward(); opt.step()
+    assert all(l == l for l in losses) and losses[-1] < losses[0] - 0.3
