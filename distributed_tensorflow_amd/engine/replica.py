@@ -23,6 +23,7 @@ from ..api.model import Model, as_model
 from ..ops.softmax_ce import softmax_ce_eval, softmax_cross_entropy
 from .flat import BucketPlanner, FlatParams
 from .reducer import GradReducer
+from ..obs.trace import phase
 
 
 @dataclass
@@ -87,7 +88,8 @@ class Replica:
         self.reducer.on_ready = on_bucket_ready
         self.reducer.grad_scale = grad_scale
         self.reducer.begin_step()
-        lv = self._loss_vector(x, y)
+        with phase("forward"):
+            lv = self._loss_vector(x, y)
         if self.cfg.loss_reduction == "sum":
             total = lv.sum()
             shown = total.detach() / max(1, lv.numel())
@@ -98,7 +100,8 @@ class Replica:
             else:
                 total = lv.mean()
             shown = total.detach()
-        total.backward()
+        with phase("backward"):
+            total.backward()
         self.step_count += 1
         return shown
 

@@ -28,6 +28,7 @@ from ..comm.backend import Comm
 from ..engine.optimizer import FlatOptimizer
 from ..engine.replica import TrainConfig
 from ..ops import bucket as bops
+from ..obs.trace import phase
 from .base import Strategy
 
 
@@ -46,11 +47,13 @@ class MirroredStrategy(Strategy):
 
     def train_step(self, x, y):
         loss = self.replica.forward_backward(x, y, self._on_ready if self.comm.world > 1 else None, self._scale)
-        for w in self.replica.finish_backward():
-            if w is not None:
-                w.wait()
-        self.optimizer.step()
-        self.apply_sparse()
+        with phase("grad_sync_wait"):
+            for w in self.replica.finish_backward():
+                if w is not None:
+                    w.wait()
+        with phase("optimizer"):
+            self.optimizer.step()
+            self.apply_sparse()
         return loss
 
 

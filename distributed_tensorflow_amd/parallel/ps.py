@@ -36,6 +36,7 @@ from ..comm.backend import Comm
 from ..engine.optimizer import FlatOptimizer
 from ..engine.replica import Replica, TrainConfig
 from ..ops import bucket as bops
+from ..obs.trace import phase
 from .base import Strategy
 
 
@@ -75,10 +76,12 @@ class SyncPSStrategy(Strategy):
         f = self.flat
         if self.apply == "reduced":
             loss = self.replica.forward_backward(x, y, self._on_ready_reduced if W > 1 else None, self._scale)
-            for w in self.replica.finish_backward():
-                if w is not None:
-                    w.wait()
-            self.optimizer.step(self.shards)
+            with phase("push_wait"):
+                for w in self.replica.finish_backward():
+                    if w is not None:
+                        w.wait()
+            with phase("ps_apply"):
+                self.optimizer.step(self.shards)
         else:
             loss = self.replica.forward_backward(x, y, None, 1.0)
             self.replica.finish_backward()
@@ -100,10 +103,11 @@ class SyncPSStrategy(Strategy):
                     opt.step(self.shards, grad=_Mapped(per_worker[w]))
         # ------------------------------------------------------------- pull
         if W > 1:
-            for b, (a, e) in zip(self.planner.buckets, self.shards):
-                self.comm.all_gather(f.master[b.start:b.end], f.master[a:e])
-                self.bytes_pulled += (b.numel - (e - a)) * 4
-            f.refresh_shadow()
+            with phase("pull"):
+                for b, (a, e) in zip(self.planner.buckets, self.shards):
+                    self.comm.all_gather(f.master[b.start:b.end], f.master[a:e])
+                    self.bytes_pulled += (b.numel - (e - a)) * 4
+                f.refresh_shadow()
         self.apply_sparse()
         return loss
 

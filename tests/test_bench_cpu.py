@@ -1,0 +1,52 @@
+"""bench.py contract: one JSON line from rank 0, launched the way the driver launches it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENV = dict(os.environ, OMP_NUM_THREADS="2", PYTHONPATH=ROOT)
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _check(line, n):
+    r = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in r, k
+    assert r["n_gpus"] == n and r["steps"] == 2 and r["warmup"] == 1
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["dtype"] == "bf16" and r["data"] == "synthetic"
+    assert r["config"]["model"] == "resnet50" and r["config"]["global_batch"] == 2 * n
+    assert r["config"]["parallelism"] == f"dp{n}"
+    assert r["value"] > 0 and abs(r["value"] - 2 * n / (r["ms_per_step"] / 1e3)) / r["value"] < 0.01
+    return r
+
+
+@pytest.mark.slow
+def test_bench_single_process_cpu_plumbing():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--device", "cpu", "--batch", "2", "--image", "32",
+                        "--steps", "2", "--warmup", "1"], env=ENV, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    _check(lines[0], 1)
+
+
+@pytest.mark.slow
+def test_bench_two_ranks_under_torchrun_gloo():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu", "--batch", "2",
+           "--image", "32", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # only rank 0 prints
+    _check(lines[0], 2)
