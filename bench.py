@@ -34,6 +34,7 @@ def main() -> int:
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--bucket-mb", type=int, default=48)
     ap.add_argument("--conv1x1", default=None, choices=[None, "gemm", "library"])
+    ap.add_argument("--convkxk", default=None, choices=[None, "gemm", "library"])
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"], help="cpu is for plumbing tests only")
     ap.add_argument("--model", default="resnet50")
     a = ap.parse_args()
@@ -58,6 +59,8 @@ def main() -> int:
         _lib.kernels()
     if a.conv1x1:
         conv.set_conv1x1_backend(a.conv1x1)
+    if a.convkxk:
+        conv.set_convkxk_backend(a.convkxk)
     comm = Comm.from_env(dev) if world > 1 else Comm(0, 1, dev)
     st = bench_lib.make_resnet50_strategy(comm, bucket_mb=a.bucket_mb)
     x, y = bench_lib.synthetic_imagenet_batch(a.batch, dev, size=a.image, seed=rank)
@@ -91,7 +94,7 @@ def main() -> int:
             "config": {"model": "resnet50", "global_batch": a.batch * world, "per_gpu_batch": a.batch,
                        "image": a.image, "seq_len": None, "parallelism": f"dp{world}",
                        "strategy": "decentralized keras-style mirrored all-reduce (bucketed, overlapped)",
-                       "optimizer": "sgd-momentum (fused flat-arena kernel)", "conv1x1": conv.get_conv1x1_backend()},
+                       "optimizer": "sgd-momentum (fused flat-arena kernel)", "conv1x1": conv.get_conv1x1_backend(), "convkxk": conv.get_convkxk_backend()},
             "final_loss": loss_v,
         }), flush=True)
     comm.shutdown()

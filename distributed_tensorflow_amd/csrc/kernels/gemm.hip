@@ -1,40 +1,51 @@
-// bf16 MFMA GEMM for gfx950 with fused epilogues, three operand layouts and split-K.
+// bf16 MFMA GEMM and implicit-GEMM convolution for gfx950: fused epilogues, three operand
+// layouts, split-K, two-level batching, NHWC convolution geometry.
 //
-//   C[M,N] = act(A x B + bias)      fp32 accumulate, bf16 or fp32 output
+//   C[M,N] = act(A x B + bias) (+ C_in)      fp32 accumulate, bf16 or fp32 output
 //
-// Layout template flags describe how each operand lies in memory relative to
-// the contraction index k:
+// Layout template flags describe how each operand lies in memory relative to the contraction
+// index k:
 //   A_T = 0 : A[m][k] (k contiguous)        A_T = 1 : A[k][m] (m contiguous)
 //   B_T = 0 : B[n][k] (k contiguous)        B_T = 1 : B[k][n] (n contiguous)
-// which covers the three products of a dense / 1x1-convolution layer:
+// which covers the three products of a dense layer:
 //   forward  y  = x  . W^T   : A_T=0, B_T=0   ("NT")
 //   dgrad    dx = dy . W     : A_T=0, B_T=1   ("NN")
 //   wgrad    dW = dy^T . x   : A_T=1, B_T=1   ("TN")
-// These are the MatMul(+BiasAdd+ReLU) ops the reference model executes inside
-// TensorFlow (reference initializer.py:16-18, centralized/client.py:12,19).
+// These are the MatMul(+BiasAdd+ReLU) ops the reference model executes inside TensorFlow
+// (reference initializer.py:16-18, centralized/client.py:12,19).
+//
+// The CONV template flag turns the same kernel into an implicit-GEMM convolution on NHWC
+// activations and [O][KH][KW][I] weights, with no im2col buffer: the operand that is an image
+// is gathered pixel by pixel while it is staged (a shifted / strided row address and a bounds
+// test per 16-byte load, zero fill outside the image):
+//   CONV=1 forward : M = output pixels, K = (kh, kw, ci), A = x gathered,  B = w            (NT)
+//   CONV=2 dgrad   : M = input pixels,  K = (kh, kw, co), A = dy gathered, B = w per tap    (NN)
+//   CONV=3 wgrad   : per tap (blockIdx.z): M = co, N = ci, K = output pixels,
+//                    A = dy, B = x gathered                                                  (TN)
+// so 1x1, 3x3, 7x7, stride 1 or 2 all run on the MFMA main loop below.
 //
 // Structure (tiled for 64-lane wavefronts, not a warp-shaped port):
-//   * 128x128 output tile per 256-thread block, BK = 64; 4 waves as 2x2, each
-//     wave owns 64x64 = 4x4 MFMA tiles of v_mfma_f32_16x16x32_bf16;
-//   * both operand tiles are staged global -> registers -> LDS in ONE image
-//     shape, [row][k] with 128-byte rows; operands whose k is the slow index
-//     are transposed in registers on the way in (4 k-rows x 8 rows per thread,
-//     written as 8-byte pieces), so the MFMA fragment reads are the same
-//     ds_read_b128 for every layout;
-//   * the 16-byte chunk index of a row is XORed with (row >> 1) & 7, which
-//     makes the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots of
-//     the 256-byte bank row (conflict-free), for writes as well;
-//   * global loads for tile t+1 are issued before the MFMAs of tile t and
-//     written to the other LDS buffer after them: one barrier per k-tile;
-//   * MFMAs are issued with swapped operands (B fragment as the A operand), so
-//     each lane ends up with 4 consecutive n of one output row; the tile is
-//     then staged through LDS and written as whole 128-byte row segments;
-//   * blockIdx is remapped so that the blocks that share an XCD (and its L2)
-//     work on neighbouring tiles.
-// Requirements checked on the host: 16-byte aligned base pointers and leading
-// dimensions that are multiples of 8 elements; M, N, K themselves are free
-// (edges are zero-filled / masked) except that a dimension that is the
-// contiguous one of a loaded or stored row must be a multiple of 8.
+//   * 128x128 output tile per 256-thread block, BK = 64; 4 waves as 2x2, each wave owns
+//     64x64 = 4x4 MFMA tiles of v_mfma_f32_16x16x32_bf16;
+//   * operand tiles are staged global -> registers -> LDS with 16-byte accesses only. A
+//     k-contiguous operand becomes a [row][k] image (128-byte rows) read with ds_read_b128; an
+//     operand whose k is the slow index keeps its memory order, a [k][row] image (256-byte rows),
+//     and its MFMA fragments are read with ds_read_b64_tr_b16, the hardware transposed read, so
+//     no register transpose and no extra LDS instructions are spent on layout;
+//   * the 16-byte chunk index is XORed with (row >> 1) & 7 in the [row][k] image and with a
+//     function of k in the [k][row] image, which makes both kinds of read conflict-free on the
+//     64-bank LDS (see swz_off / swz_t);
+//   * global loads for tile t+1 are issued before the MFMAs of tile t and written to the other
+//     LDS buffer after them: one barrier per k-tile;
+//   * MFMAs are issued with swapped operands (B fragment as the A operand), so each lane ends up
+//     with 4 consecutive n of one output row; the tile is then staged through LDS and written as
+//     whole 128-byte row segments (optionally adding an existing tensor C_in on the way out:
+//     the residual-branch gradient accumulation of a ResNet block);
+//   * blockIdx is remapped so that the blocks that share an XCD (and its L2) work on
+//     neighbouring tiles.
+// Requirements checked on the host: 16-byte aligned base pointers, leading dimensions and
+// channel counts that are multiples of 8 elements; M and K are otherwise free (edges are
+// zero-filled / masked).
 #include "dtf_common.h"
 
 using namespace dtf;
@@ -42,16 +53,25 @@ using namespace dtf;
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kThreads = 256;
 constexpr int kTileBytes = BM * BK * 2;  // 16 KiB per operand tile
 
+// Convolution geometry (NHWC). x: [N][H][W][CI], dy / y: [N][OH][OW][CO], w: [CO][KH][KW][CI].
+struct ConvGeom {
+  int H, W, OH, OW, S, P, KH, KW, CI, CO;
+  float r_ohw, r_ow, r_hw, r_w, r_ci, r_co, r_kw;   // reciprocals for the exact float divmod below
+};
+
 struct GemmArgs {
   const unsigned short* A;
   const unsigned short* B;
-  void* C;               // bf16 or fp32 [M][ldc]; fp32 [splits][M][N] workspace when splits > 1
+  void* C;               // bf16 or fp32 [M][ldc]; fp32 [splits][batch][M][N] workspace when splits > 1
   const void* bias;      // [N] or null
+  const unsigned short* Cin;  // optional bf16 tensor added to the result (same indexing as C)
   long long lda, ldb, ldc;
   int M, N, K;
   int k_per_split;       // multiple of BK
@@ -63,99 +83,178 @@ struct GemmArgs {
   // batched GEMM: blockIdx.z = b1 * nb2 + b2; operand offsets b1 * s?1 + b2 * s?2 (elements)
   int nb2;
   long long sA1, sA2, sB1, sB2, sC1, sC2;
-  // pixel map of a strided 1x1 convolution: logical row r = (n, oh, ow) of the OUTPUT resolution
-  // addresses memory row (n*H + oh*S)*W + ow*S. map_mask bit 0: A's pixel index, bit 1: B's pixel
-  // index, bit 2: C's rows (the caller zero-fills C first).
-  int map_mask;
-  int mOW, mOH, mW, mH, mS;
+  ConvGeom cv;
 };
 
-__device__ __forceinline__ long long map_row(const GemmArgs& g, int r) {
-  const int hw = g.mOH * g.mOW;
-  const int n = r / hw, rem = r - n * hw;
-  const int oh = rem / g.mOW, ow = rem - oh * g.mOW;
-  return ((long long)n * g.mH + (long long)oh * g.mS) * g.mW + (long long)ow * g.mS;
+// q = x / d, r = x % d for 0 <= x < 2^24 with rcp = 1/d: float estimate plus one correction.
+__device__ __forceinline__ void divmod(int x, int d, float rcp, int& q, int& r) {
+  q = (int)((float)x * rcp);
+  r = x - q * d;
+  if (r < 0) { --q; r += d; }
+  else if (r >= d) { ++q; r -= d; }
 }
 
 __device__ __forceinline__ int swz_off(int row, int chunk) {
   return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
+// LDS image of a row-contiguous operand: [k][row] with 256-byte k-rows, stored as loaded. The
+// 16-byte chunk index is XORed with swz_t(k) so that the eight k-rows a 32-lane half touches in
+// one ds_read_b64_tr_b16 (k&3 = 0..3 for two values of (k>>3)&1) fall on eight different 32-byte
+// slots of the 256-byte bank row: conflict-free transposed reads.
+__device__ __forceinline__ int swz_t(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
 
-// ---- staging: global -> registers -------------------------------------------------
-// k-contiguous operand X[row][k]: thread handles chunk ids tid + 256*i: row = id >> 3, chunk = id & 7.
-__device__ __forceinline__ void stage_load_kmajor(const GemmArgs& g, bool mapped, const unsigned short* __restrict__ X,
-                                                  long long ld, int rows, int row0, int k0, int kend, u32x4 (&r)[4]) {
+// ---------------------------------------------------------------------------------------------
+// Operand stagers. Each thread owns 4 x 16-byte chunks of a tile. Per-row geometry that does not
+// depend on the k-tile is computed once in init() and kept in registers.
+//
+// k-contiguous image ([row][k]): chunk ids tid + 256*i -> row = id >> 3, k-chunk = id & 7 (the
+// same k-chunk for all 4 chunks of a thread, 32 rows apart).
+// row-contiguous image ([k][row]): row-chunk rc = tid & 15 (rows rc*8..+7), k = (tid >> 4)*4 + i.
+
+template <int T, int GATHER>   // GATHER: 0 plain, 1 conv forward x, 2 conv dgrad dy, 3 conv wgrad x, 4 conv dgrad w
+struct Stager {
+  u32x4 r[4];
+  int base[4];       // pixel index base (GATHER 1, 2)
+  int ca[4], cb[4];  // ih0 / iw0 (GATHER 1) or ih+P / iw+P (GATHER 2)
+  bool rowok[4];
+
+  __device__ __forceinline__ void init(const GemmArgs& g, int rows, int row0) {
+    if (T == 0 && (GATHER == 1 || GATHER == 2)) {
+      const ConvGeom& c = g.cv;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int id = threadIdx.x + kThreads * i;
-    const int row = row0 + (id >> 3);
-    const int k = k0 + ((id & 7) << 3);
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < rows && k < kend) {
-      const long long mr = mapped ? map_row(g, row) : (long long)row;
-      v = *reinterpret_cast<const u32x4*>(X + mr * ld + k);
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + ((threadIdx.x + kThreads * i) >> 3);
+        rowok[i] = row < rows;
+        const int m = rowok[i] ? row : 0;
+        int n, rem, a, b;
+        if (GATHER == 1) {                  // m = (n, oh, ow)
+          divmod(m, c.OH * c.OW, c.r_ohw, n, rem);
+          divmod(rem, c.OW, c.r_ow, a, b);
+          ca[i] = a * c.S - c.P; cb[i] = b * c.S - c.P;
+          base[i] = (n * c.H + ca[i]) * c.W + cb[i];
+        } else {                            // m = (n, ih, iw)
+          divmod(m, c.H * c.W, c.r_hw, n, rem);
+          divmod(rem, c.W, c.r_w, a, b);
+          ca[i] = a + c.P; cb[i] = b + c.P;
+          base[i] = n * c.OH * c.OW;
+        }
+      }
     }
-    r[i] = v;
   }
-}
 
-__device__ __forceinline__ void stage_store_kmajor(char* lds, const u32x4 (&r)[4]) {
+  __device__ __forceinline__ void load(const GemmArgs& g, const unsigned short* __restrict__ X, long long ld, int rows,
+                                       int row0, int k0, int kend, int tap) {
+    const ConvGeom& c = g.cv;
+    if (T == 0) {
+      const int k = k0 + ((threadIdx.x & 7) << 3);
+      const bool kok = k < kend;
+      if (GATHER == 0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int id = threadIdx.x + kThreads * i;
-    *reinterpret_cast<u32x4*>(lds + swz_off(id >> 3, id & 7)) = r[i];
-  }
-}
-
-// row-contiguous operand X[k][row]: thread handles row-chunk rc = tid & 15 (rows rc*8..+7) and the
-// four k-rows kg*4 .. kg*4+3 with kg = tid >> 4.
-__device__ __forceinline__ void stage_load_rmajor(const GemmArgs& g, bool mapped, const unsigned short* __restrict__ X,
-                                                  long long ld, int rows, int row0, int k0, int kend, u32x4 (&r)[4]) {
-  const int rc = threadIdx.x & 15, kg = threadIdx.x >> 4;
-  const int row = row0 + (rc << 3);
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + ((threadIdx.x + kThreads * i) >> 3);
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (row < rows && kok) v = *reinterpret_cast<const u32x4*>(X + (long long)row * ld + k);
+          r[i] = v;
+        }
+      } else if (GATHER == 1) {             // k = (kh, kw, ci)
+        int t, ci, kh, kw;
+        divmod(kok ? k : 0, c.CI, c.r_ci, t, ci);
+        divmod(t, c.KW, c.r_kw, kh, kw);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = k0 + kg * 4 + i;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < rows && k < kend) {
-      const long long mk = mapped ? map_row(g, k) : (long long)k;   // the pixel index is the contraction index here
-      v = *reinterpret_cast<const u32x4*>(X + mk * ld + row);
+        for (int i = 0; i < 4; ++i) {
+          const int ih = ca[i] + kh, iw = cb[i] + kw;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (rowok[i] && kok && ih >= 0 && ih < c.H && iw >= 0 && iw < c.W)
+            v = *reinterpret_cast<const u32x4*>(X + (long long)(base[i] + kh * c.W + kw) * c.CI + ci);
+          r[i] = v;
+        }
+      } else {                              // GATHER 2: k = (kh, kw, co), source pixel ((ih+P-kh)/S, (iw+P-kw)/S)
+        int t, co, kh, kw;
+        divmod(kok ? k : 0, c.CO, c.r_co, t, co);
+        divmod(t, c.KW, c.r_kw, kh, kw);
+        const int sm = c.S - 1, sh = c.S >> 1;   // S is 1 or 2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int th = ca[i] - kh, tw = cb[i] - kw;
+          const int oh = th >> sh, ow = tw >> sh;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (rowok[i] && kok && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && oh < c.OH && ow < c.OW)
+            v = *reinterpret_cast<const u32x4*>(X + (long long)(base[i] + oh * c.OW + ow) * c.CO + co);
+          r[i] = v;
+        }
+      }
+    } else {
+      const int rc = threadIdx.x & 15, kg = threadIdx.x >> 4;
+      const int row = row0 + (rc << 3);
+      const bool rok = row < rows;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + kg * 4 + i;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (rok && k < kend) {
+          if (GATHER == 0) {
+            v = *reinterpret_cast<const u32x4*>(X + (long long)k * ld + row);
+          } else if (GATHER == 4) {         // weights for dgrad: k = (tap, co) -> w[co][tap][ci = row]
+            int t, co;
+            divmod(k, c.CO, c.r_co, t, co);
+            v = *reinterpret_cast<const u32x4*>(X + (long long)co * ld + t * c.CI + row);
+          } else {                          // GATHER 3: k = output pixel, tap fixed: x[(n, oh*S+kh-P, ow*S+kw-P)][row]
+            int n, rem, oh, ow, kh, kw;
+            divmod(k, c.OH * c.OW, c.r_ohw, n, rem);
+            divmod(rem, c.OW, c.r_ow, oh, ow);
+            divmod(tap, c.KW, c.r_kw, kh, kw);
+            const int ih = oh * c.S + kh - c.P, iw = ow * c.S + kw - c.P;
+            if (ih >= 0 && ih < c.H && iw >= 0 && iw < c.W)
+              v = *reinterpret_cast<const u32x4*>(X + (long long)((n * c.H + ih) * c.W + iw) * c.CI + row);
+          }
+        }
+        r[i] = v;
+      }
     }
-    r[i] = v;
   }
-}
 
-__device__ __forceinline__ void stage_store_rmajor(char* lds, const u32x4 (&r)[4]) {
-  const int rc = threadIdx.x & 15, kg = threadIdx.x >> 4;
-  const int chunk = kg >> 1, half = kg & 1;
+  __device__ __forceinline__ void store(char* lds) const {
+    if (T == 0) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int w = j >> 1, sh = (j & 1) * 16;
-    const unsigned e0 = (r[0][w] >> sh) & 0xffffu, e1 = (r[1][w] >> sh) & 0xffffu;
-    const unsigned e2 = (r[2][w] >> sh) & 0xffffu, e3 = (r[3][w] >> sh) & 0xffffu;
-    u32x2 o;
-    o[0] = e0 | (e1 << 16);
-    o[1] = e2 | (e3 << 16);
-    const int row = (rc << 3) + j;
-    *reinterpret_cast<u32x2*>(lds + swz_off(row, chunk) + (half << 3)) = o;
+      for (int i = 0; i < 4; ++i) {
+        const int id = threadIdx.x + kThreads * i;
+        *reinterpret_cast<u32x4*>(lds + swz_off(id >> 3, id & 7)) = r[i];
+      }
+    } else {
+      const int rc = threadIdx.x & 15, kg = threadIdx.x >> 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = kg * 4 + i;
+        *reinterpret_cast<u32x4*>(lds + k * 256 + ((rc ^ swz_t(k)) << 4)) = r[i];
+      }
+    }
   }
-}
+};
 
+// MFMA operand fragment (row = row0 + (lane & 15), k = ks*32 + 8*(lane >> 4) + 0..7) of a tile.
+// T = 0: [row][k] image, one ds_read_b128. T = 1: [k][row] image, two hardware-transposed reads
+// (each returns 4 consecutive k of this lane's row).
 template <int T>
-__device__ __forceinline__ void stage_load(const GemmArgs& g, bool mapped, const unsigned short* X, long long ld, int rows,
-                                           int row0, int k0, int kend, u32x4 (&r)[4]) {
-  if (T == 0) stage_load_kmajor(g, mapped, X, ld, rows, row0, k0, kend, r);
-  else stage_load_rmajor(g, mapped, X, ld, rows, row0, k0, kend, r);
-}
-template <int T>
-__device__ __forceinline__ void stage_store(char* lds, const u32x4 (&r)[4]) {
-  if (T == 0) stage_store_kmajor(lds, r);
-  else stage_store_rmajor(lds, r);
+__device__ __forceinline__ bf16x8_t load_frag(const char* lds, int row0, int ks, int lane) {
+  if (T == 0) {
+    const int row = row0 + (lane & 15);
+    return *reinterpret_cast<const bf16x8_t*>(lds + swz_off(row, ks * 4 + (lane >> 4)));
+  } else {
+    const int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
+    const int k = ks * 32 + 8 * g + q;
+    const int chunk = (row0 >> 3) + (p >> 1);
+    const int off = k * 256 + ((chunk ^ swz_t(k)) << 4) + ((p & 1) << 3);
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(lds + off));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(lds + off + 4 * 256));  // k + 4: same swizzle
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <int A_T, int B_T>
+template <int A_T, int B_T, int CONV>
 __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 tiles: A0 B0 A1 B1 (64 KiB)
 
@@ -171,7 +270,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   const unsigned short* Ap = g.A + b1 * g.sA1 + b2 * g.sA2;
   const unsigned short* Bp = g.B + b1 * g.sB1 + b2 * g.sB2;
   const long long c_off = b1 * g.sC1 + b2 * g.sC2;
-  const bool mapA = g.map_mask & 1, mapB = g.map_mask & 2, mapC = g.map_mask & 4;
+  const int tap = blockIdx.z;            // CONV 3: one launch plane per filter tap
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nt = (kend - kbeg + BK - 1) / BK;
@@ -186,12 +285,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[4], rb[4];
+  constexpr int GA = CONV == 1 ? 1 : CONV == 2 ? 2 : 0;
+  constexpr int GB = CONV == 2 ? 4 : CONV == 3 ? 3 : 0;
+  Stager<A_T, GA> sa;
+  Stager<B_T, GB> sb;
+  sa.init(g, g.M, m0);
+  sb.init(g, g.N, n0);
   if (nt > 0) {
-    stage_load<A_T>(g, mapA, Ap, g.lda, g.M, m0, kbeg, kend, ra);
-    stage_load<B_T>(g, mapB, Bp, g.ldb, g.N, n0, kbeg, kend, rb);
-    stage_store<A_T>(smem, ra);
-    stage_store<B_T>(smem + kTileBytes, rb);
+    sa.load(g, Ap, g.lda, g.M, m0, kbeg, kend, tap);
+    sb.load(g, Bp, g.ldb, g.N, n0, kbeg, kend, tap);
+    sa.store(smem);
+    sb.store(smem + kTileBytes);
   }
   __syncthreads();
 
@@ -200,25 +304,18 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     const bool more = (t + 1) < nt;
     if (more) {
       const int k0 = kbeg + (t + 1) * BK;
-      stage_load<A_T>(g, mapA, Ap, g.lda, g.M, m0, k0, kend, ra);
-      stage_load<B_T>(g, mapB, Bp, g.ldb, g.N, n0, k0, kend, rb);
+      sa.load(g, Ap, g.lda, g.M, m0, k0, kend, tap);
+      sb.load(g, Bp, g.ldb, g.N, n0, k0, kend, tap);
     }
     const char* la = smem + cur * 2 * kTileBytes;
     const char* lb = la + kTileBytes;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t a[4], b[4];
-      const int chunk = ks * 4 + fq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wm * 64 + i * 16 + fr;
-        a[i] = *reinterpret_cast<const bf16x8_t*>(la + swz_off(row, chunk));
-      }
+      for (int i = 0; i < 4; ++i) a[i] = load_frag<A_T>(la, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wn * 64 + j * 16 + fr;
-        b[j] = *reinterpret_cast<const bf16x8_t*>(lb + swz_off(row, chunk));
-      }
+      for (int j = 0; j < 4; ++j) b[j] = load_frag<B_T>(lb, wn * 64 + j * 16, ks, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -228,8 +325,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
     if (more) {
       char* na = smem + (cur ^ 1) * 2 * kTileBytes;
-      stage_store<A_T>(na, ra);
-      stage_store<B_T>(na + kTileBytes, rb);
+      sa.store(na);
+      sb.store(na + kTileBytes);
     }
     __syncthreads();
     cur ^= 1;
@@ -238,8 +335,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   // ---- epilogue ---------------------------------------------------------------------
   const int wm0 = m0 + wm * 64, wn0 = n0 + wn * 64;
   if (g.splits > 1) {
-    // fp32 partial slab [split][M][N]; 16 bytes per lane, 4 consecutive n
-    float* W = reinterpret_cast<float*>(g.C) + (long long)split * g.M * g.N;
+    // fp32 partial slab [split][batch][M][N]; 16 bytes per lane, 4 consecutive n
+    float* W = reinterpret_cast<float*>(g.C) + ((long long)split * gridDim.z + blockIdx.z) * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = wm0 + i * 16 + fr;
@@ -284,11 +381,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     for (int i = 0; i < 4; ++i) {
       const int m = wm0 + i * 16 + fr;
       if (m >= g.M) continue;
-      const long long mr = mapC ? map_row(g, m) : (long long)m;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = wn0 + j * 16 + fq * 4;
-        if (n < g.N) *reinterpret_cast<f32x4*>(C + mr * g.ldc + n) = acc[i][j];
+        if (n < g.N) *reinterpret_cast<f32x4*>(C + (long long)m * g.ldc + n) = acc[i][j];
       }
     }
     return;
@@ -311,51 +407,86 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   }
   __syncthreads();
   unsigned short* C = reinterpret_cast<unsigned short*>(g.C) + c_off;
+  const unsigned short* Cin = g.Cin ? g.Cin + c_off : nullptr;
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int id = lane + 64 * p;
     const int row = id >> 3, chunk = id & 7;
     const int m = wm0 + row, n = wn0 + chunk * 8;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(stage + swz_off(row, chunk));
+    u32x4 v = *reinterpret_cast<const u32x4*>(stage + swz_off(row, chunk));
     if (m < g.M && n < g.N) {
-      const long long mr = mapC ? map_row(g, m) : (long long)m;
-      *reinterpret_cast<u32x4*>(C + mr * g.ldc + n) = v;
+      if (Cin) {
+        // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
+        const u32x4 c = *reinterpret_cast<const u32x4*>(Cin + (long long)m * g.ldc + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float(v[e] << 16) + __uint_as_float(c[e] << 16);
+          const float hi = __uint_as_float(v[e] & 0xffff0000u) + __uint_as_float(c[e] & 0xffff0000u);
+          v[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+        }
+      }
+      *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + n) = v;
     }
   }
 }
 
-// Sum split-K slabs, add bias, activate, convert. One thread per 4 consecutive n.
+// Sum split-K slabs, add bias, activate, convert. A block owns 16 consecutive float4 outputs;
+// its 16 split-lanes each sum every 16th slab (4 loads in flight), then combine through LDS in a
+// fixed order, so the result does not depend on scheduling. blockIdx.y = batch plane.
 __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const float* __restrict__ W, void* __restrict__ C,
                                                                const void* __restrict__ bias, int bias_dtype, int act,
-                                                               int out_fp32, int splits, int M, int N, long long ldc) {
+                                                               int out_fp32, int splits, int M, int N, long long ldc,
+                                                               long long c_batch_stride) {
+  __shared__ f32x4 red[16][17];
+  const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const long long n4 = (long long)M * (N >> 2);
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  const long long slab = (long long)M * N;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const int m = (int)(i / (N >> 2));
-    const int n = (int)(i % (N >> 2)) << 2;
-    f32x4 s = *reinterpret_cast<const f32x4*>(W + (long long)m * N + n);
-    for (int k = 1; k < splits; ++k) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(W + k * slab + (long long)m * N + n);
-      s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+  const long long plane = (long long)M * N;
+  const long long slab = plane * gridDim.y;
+  W += (long long)blockIdx.y * plane;
+  const long long c_off = (long long)blockIdx.y * c_batch_stride;
+  for (long long base = (long long)blockIdx.x * 16; base < n4; base += (long long)gridDim.x * 16) {
+    const long long i = base + ol;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int m = 0, n = 0;
+    if (i < n4) {
+      m = (int)(i / (N >> 2));
+      n = (int)(i % (N >> 2)) << 2;
+      const float* p = W + (long long)m * N + n;
+      int k = sl;
+      for (; k + 48 < splits; k += 64) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + k * slab);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p + (k + 16) * slab);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p + (k + 32) * slab);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(p + (k + 48) * slab);
+        s += (a + b) + (c + d);
+      }
+      for (; k < splits; k += 16) s += *reinterpret_cast<const f32x4*>(p + k * slab);
     }
-    if (bias) {
+    __syncthreads();
+    red[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && i < n4) {
+      s = red[0][ol];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        s[r] += bias_dtype == 0 ? reinterpret_cast<const float*>(bias)[n + r]
-                                : bf16_to_f32(reinterpret_cast<const unsigned short*>(bias)[n + r]);
-    }
+      for (int r = 1; r < 16; ++r) s += red[r][ol];
+      if (bias) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (act == 1) s[r] = fmaxf(s[r], 0.f);
-      else if (act == 2) s[r] = gelu_erf(s[r]);
-    }
-    if (out_fp32) {
-      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (long long)m * ldc + n) = s;
-    } else {
-      u16x4 o;
-      o[0] = f32_to_bf16(s[0]); o[1] = f32_to_bf16(s[1]); o[2] = f32_to_bf16(s[2]); o[3] = f32_to_bf16(s[3]);
-      *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(C) + (long long)m * ldc + n) = o;
+        for (int r = 0; r < 4; ++r)
+          s[r] += bias_dtype == 0 ? reinterpret_cast<const float*>(bias)[n + r]
+                                  : bf16_to_f32(reinterpret_cast<const unsigned short*>(bias)[n + r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (act == 1) s[r] = fmaxf(s[r], 0.f);
+        else if (act == 2) s[r] = gelu_erf(s[r]);
+      }
+      if (out_fp32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + c_off + (long long)m * ldc + n) = s;
+      } else {
+        u16x4 o;
+        o[0] = f32_to_bf16(s[0]); o[1] = f32_to_bf16(s[1]); o[2] = f32_to_bf16(s[2]); o[3] = f32_to_bf16(s[3]);
+        *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(C) + c_off + (long long)m * ldc + n) = o;
+      }
     }
   }
 }
@@ -364,7 +495,9 @@ __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const float* __re
 struct GemmExtra {
   int nb1, nb2;                      // batch = nb1 * nb2 (0 or 1 = not batched)
   long long sA1, sA2, sB1, sB2, sC1, sC2;
-  int map_mask, mOW, mOH, mW, mH, mS;
+  int conv;                          // 0 plain, 1 conv forward, 2 conv dgrad, 3 conv wgrad
+  int H, W, OH, OW, S, P, KH, KW, CI, CO;
+  const void* Cin;                   // optional bf16 tensor added to the output
 };
 
 static int gemm_launch(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
@@ -374,21 +507,31 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   if (splits < 1) splits = 1;
   GemmArgs g;
   g.A = (const unsigned short*)A; g.B = (const unsigned short*)B;
-  g.bias = bias; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.bias = bias; g.Cin = nullptr; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.bias_dtype = bias_dtype; g.act = act; g.out_fp32 = out_fp32;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
-  int batch = 1;
+  int batch = 1, conv = 0;
   g.nb2 = 1; g.sA1 = g.sA2 = g.sB1 = g.sB2 = g.sC1 = g.sC2 = 0;
-  g.map_mask = 0; g.mOW = g.mOH = g.mW = g.mH = g.mS = 1;
+  ConvGeom& c = g.cv;
+  c.H = c.W = c.OH = c.OW = c.S = c.KH = c.KW = c.CI = c.CO = 1; c.P = 0;
   if (ex) {
     const int nb1 = ex->nb1 > 0 ? ex->nb1 : 1;
     g.nb2 = ex->nb2 > 0 ? ex->nb2 : 1;
     batch = nb1 * g.nb2;
     g.sA1 = ex->sA1; g.sA2 = ex->sA2; g.sB1 = ex->sB1; g.sB2 = ex->sB2; g.sC1 = ex->sC1; g.sC2 = ex->sC2;
-    g.map_mask = ex->map_mask;
-    if (g.map_mask) { g.mOW = ex->mOW; g.mOH = ex->mOH; g.mW = ex->mW; g.mH = ex->mH; g.mS = ex->mS; }
+    g.Cin = (const unsigned short*)ex->Cin;
+    conv = ex->conv;
+    if (conv) {
+      c.H = ex->H; c.W = ex->W; c.OH = ex->OH; c.OW = ex->OW; c.S = ex->S; c.P = ex->P; c.KH = ex->KH; c.KW = ex->KW;
+      c.CI = ex->CI; c.CO = ex->CO;
+      if (c.S != 1 && c.S != 2) return -4;
+      if ((long long)M >= (1 << 24) || (long long)K >= (1 << 24)) return -5;   // float divmod range
+    }
   }
-  if (batch > 1 || (g.map_mask & 4)) splits = 1;   // split-K slabs are neither batched nor row-mapped
+  c.r_ohw = 1.f / (float)(c.OH * c.OW); c.r_ow = 1.f / (float)c.OW; c.r_hw = 1.f / (float)(c.H * c.W);
+  c.r_w = 1.f / (float)c.W; c.r_ci = 1.f / (float)c.CI; c.r_co = 1.f / (float)c.CO; c.r_kw = 1.f / (float)c.KW;
+  if (g.Cin && out_fp32) return -6;
+  if (g.Cin || (batch > 1 && conv != 3)) splits = 1;   // slabs carry neither C_in nor strided batches
   int kps = ((K + splits - 1) / splits + BK - 1) / BK * BK;
   splits = (K + kps - 1) / kps;
   g.k_per_split = kps; g.splits = splits;
@@ -396,21 +539,29 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   if (splits > 1 && !workspace) return -3;
   const dim3 grid(g.tiles_m * g.tiles_n, splits, batch);
   const size_t lds = 4 * kTileBytes;
-  switch (layout) {
-    case 0: hipLaunchKernelGGL((gemm_bf16_kernel<0, 0>), grid, dim3(kThreads), lds, stream, g); break;
-    case 1: hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, dim3(kThreads), lds, stream, g); break;
-    case 2: hipLaunchKernelGGL((gemm_bf16_kernel<1, 1>), grid, dim3(kThreads), lds, stream, g); break;
-    default: return -1;
-  }
+#define GEMM_LAUNCH(AT, BT, CV) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV>), grid, dim3(kThreads), lds, stream, g)
+  if (conv == 0) {
+    switch (layout) {
+      case 0: GEMM_LAUNCH(0, 0, 0); break;
+      case 1: GEMM_LAUNCH(0, 1, 0); break;
+      case 2: GEMM_LAUNCH(1, 1, 0); break;
+      default: return -1;
+    }
+  } else if (conv == 1 && layout == 0) GEMM_LAUNCH(0, 0, 1);
+  else if (conv == 2 && layout == 1) GEMM_LAUNCH(0, 1, 2);
+  else if (conv == 3 && layout == 2) GEMM_LAUNCH(1, 1, 3);
+  else return -1;
+#undef GEMM_LAUNCH
   if (splits > 1) {
     const long long n4 = (long long)M * (N / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n4, kBlock)), dim3(kBlock), 0, stream,
-                       (const float*)workspace, C, bias, bias_dtype, act, out_fp32, splits, M, N, ldc);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n4, 16), batch), dim3(kBlock), 0, stream,
+                       (const float*)workspace, C, bias, bias_dtype, act, out_fp32, splits, M, N, ldc, g.sC2);
   }
   return (int)hipGetLastError();
 }
 
-// layout: 0 = NT, 1 = NN, 2 = TN (see the header comment). workspace: fp32, >= splits*M*N floats when splits > 1.
+// layout: 0 = NT, 1 = NN, 2 = TN (see the header comment). workspace: fp32, >= splits*batch*M*N floats
+// when splits > 1.
 DTF_API int dtf_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                           long long lda, long long ldb, long long ldc, int bias_dtype, int act, int out_fp32,
                           int splits, void* workspace, hipStream_t stream) {
@@ -418,7 +569,7 @@ DTF_API int dtf_gemm_bf16(int layout, const void* A, const void* B, void* C, con
                      nullptr, stream);
 }
 
-// Batched and/or pixel-mapped variant; `ex` points to a GemmExtra.
+// Batched / convolution / accumulate variant; `ex` points to a GemmExtra.
 DTF_API int dtf_gemm_bf16_ex(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                              long long lda, long long ldb, long long ldc, int bias_dtype, int act, int out_fp32,
                              int splits, void* workspace, const void* ex, hipStream_t stream) {

@@ -45,7 +45,9 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short
                                                             const unsigned short* __restrict__ dy,
                                                             const unsigned short* __restrict__ y,
                                                             const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, float* __restrict__ part,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ part,
                                                             long long M, int C, int relu) {
   __shared__ float red[2][kBlock][8];
   const int cchunk = min(C, 2048);
@@ -55,8 +57,11 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short
   const int c0 = blockIdx.y * 2048 + tc * 8;
   const bool live = tr < rpb && c0 < C;
   float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float mu[8], is[8];
-  if (MODE == 1 && live) { ld8f(mean + c0, mu); ld8f(invstd + c0, is); }
+  float mu[8], is[8], sa[8], sb[8];
+  if (MODE == 1 && live) {
+    ld8f(mean + c0, mu); ld8f(invstd + c0, is);
+    if (relu == 2) { ld8f(scale + c0, sa); ld8f(shift + c0, sb); }
+  }
   if (live) {
     const long long rstride = (long long)gridDim.x * rpb;
     for (long long r = (long long)blockIdx.x * rpb + tr; r < M; r += rstride) {
@@ -68,11 +73,15 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short
       } else {
         float g[8];
         ld8bf(dy + r * C + c0, g);
-        if (relu) {
+        if (relu == 1) {
           float o[8];
           ld8bf(y + r * C + c0, o);
 #pragma unroll
           for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+        } else if (relu == 2) {
+          // no residual: the forward output was relu(fma(x, scale, shift)); recompute its sign from x
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[k] = fmaf(v[k], sa[k], sb[k]) > 0.f ? g[k] : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s0[k] += g[k]; s1[k] = fmaf(g[k], (v[k] - mu[k]) * is[k], s1[k]); }
@@ -202,6 +211,8 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(const unsigned sho
                                                               const unsigned short* __restrict__ y,
                                                               const float* __restrict__ cA, const float* __restrict__ cK,
                                                               const float* __restrict__ c0,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
                                                               unsigned short* __restrict__ dx,
                                                               unsigned short* __restrict__ dres, long long M, int C,
                                                               int relu) {
@@ -213,11 +224,16 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(const unsigned sho
     float v[8], g[8], a[8], kk[8], z[8];
     ld8bf(x + i * 8, v); ld8bf(dy + i * 8, g);
     ld8f(cA + c, a); ld8f(cK + c, kk); ld8f(c0 + c, z);
-    if (relu) {
+    if (relu == 1) {
       float o[8];
       ld8bf(y + i * 8, o);
 #pragma unroll
       for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+    } else if (relu == 2) {
+      float sa[8], sb[8];
+      ld8f(scale + c, sa); ld8f(shift + c, sb);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = fmaf(v[k], sa[k], sb[k]) > 0.f ? g[k] : 0.f;
     }
     if (dres) st8bf(dres + i * 8, g);
 #pragma unroll
@@ -249,7 +265,7 @@ DTF_API int dtf_bn_fwd_train(const void* x, const void* res, void* y, const floa
   const int nb = bn_partials_for(M, C);
   const dim3 grid(nb, (C + 2047) / 2048);
   hipLaunchKernelGGL(bn_partial_kernel<0>, grid, dim3(kBlock), 0, stream, (const unsigned short*)x, nullptr, nullptr,
-                     nullptr, nullptr, workspace, M, C, 0);
+                     nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, workspace, nb, gamma, beta,
                      run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
@@ -266,20 +282,23 @@ DTF_API int dtf_bn_fwd_apply(const void* x, const void* res, void* y, const floa
   return (int)hipGetLastError();
 }
 
-// coef: fp32 [3 * C] scratch (A, K, C0).
+// coef: fp32 [3 * C] scratch (A, K, C0). relu: 0 none, 1 mask from the saved output y, 2 mask recomputed
+// from x with the forward's scale/shift (layers without a residual input; y is not read at all).
 DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* mean,
-                       const float* invstd, void* dx, void* dres, float* dgamma, float* dbeta, float* coef,
-                       float* workspace, long long M, int C, int relu, hipStream_t stream) {
+                       const float* invstd, const float* scale, const float* shift, void* dx, void* dres,
+                       float* dgamma, float* dbeta, float* coef, float* workspace, long long M, int C, int relu,
+                       hipStream_t stream) {
   if (M <= 0 || C <= 0) return 0;
   if (C % 8) return -1;
   const int nb = bn_partials_for(M, C);
   const dim3 grid(nb, (C + 2047) / 2048);
   hipLaunchKernelGGL(bn_partial_kernel<1>, grid, dim3(kBlock), 0, stream, (const unsigned short*)x,
-                     (const unsigned short*)dy, (const unsigned short*)y, mean, invstd, workspace, M, C, relu);
+                     (const unsigned short*)dy, (const unsigned short*)y, mean, invstd, scale, shift, workspace, M, C,
+                     relu);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, workspace, nb, gamma, mean,
                      invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C);
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,
-                     coef + 2 * C, (unsigned short*)dx, (unsigned short*)dres, M, C, relu);
+                     coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C, relu);
   return (int)hipGetLastError();
 }

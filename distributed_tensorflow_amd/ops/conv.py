@@ -1,15 +1,15 @@
 """2-D convolution front end for channels_last (NHWC) activations.
 
 Routing:
-* 1x1 convolutions (two thirds of ResNet-50's layers) ARE matrix products on NHWC data:
-  ``y[N*H*W, Cout] = x[N*H*W, Cin] @ w[Cout, Cin]^T``. With bf16 operands they run on the
-  hand-written MFMA GEMM (``ops/gemm.py``): forward, data gradient and the split-K weight
-  gradient, with no im2col and no layout change. A stride-2 1x1 convolution first gathers
-  the strided pixels.
-* everything else goes to the vendor convolution library through ``torch.nn.functional``.
+* bf16 convolutions whose channel counts are multiples of 8 (every ResNet layer but the 3-channel
+  stem) run on the hand-written MFMA kernel (``csrc/kernels/gemm.hip``): forward, data gradient
+  and split-K weight gradient are implicit GEMMs on the NHWC bytes. A 1x1 stride-1 convolution
+  (two thirds of ResNet-50's layers) is literally ``y[N*H*W, Cout] = x[N*H*W, Cin] @ w^T``;
+  larger kernels and strides gather the shifted / strided pixels while the operand is staged.
+* everything else (the stem, fp32, odd channel counts) goes to the vendor convolution library.
 
-``set_conv1x1_backend('gemm' | 'library')`` switches the 1x1 route (default from the
-``DTF_CONV1X1`` environment variable, ``gemm``).
+``set_conv1x1_backend`` / ``set_convkxk_backend`` (``'gemm' | 'library'``, defaults from the
+``DTF_CONV1X1`` / ``DTF_CONVKXK`` environment variables) switch the routes, e.g. for A/B timing.
 """
 from __future__ import annotations
 
@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from . import gemm as _gemm
 
 _backend = os.environ.get("DTF_CONV1X1", "gemm")
+_backend_kxk = os.environ.get("DTF_CONVKXK", "library")
 
 
 def set_conv1x1_backend(name: str) -> None:
@@ -34,58 +35,82 @@ def get_conv1x1_backend() -> str:
     return _backend
 
 
-class _Conv1x1Fn(torch.autograd.Function):
-    """1x1 convolution, stride s >= 1, as three GEMMs on the NHWC bytes. With a stride the GEMM
-    reads (forward, weight gradient) or writes (data gradient) only the strided pixels through the
-    kernel's row map, so no gathered copy of the activation is ever made."""
+def set_convkxk_backend(name: str) -> None:
+    """Route of convolutions with a kernel larger than 1x1: 'gemm' (implicit GEMM on the MFMA kernel)
+    or 'library' (vendor convolution library)."""
+    global _backend_kxk
+    if name not in ("gemm", "library"):
+        raise ValueError("backend must be 'gemm' or 'library'")
+    _backend_kxk = name
+
+
+def get_convkxk_backend() -> str:
+    return _backend_kxk
+
+
+class _ConvFn(torch.autograd.Function):
+    """k x k convolution (stride 1 or 2) as three implicit-GEMM launches on the NHWC bytes: the image
+    operand is gathered pixel by pixel while it is staged into LDS, so there is no im2col buffer, no
+    gathered copy for strides and no layout change. ``grad_add`` (optional) is a tensor that the data
+    gradient is accumulated onto inside the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, stride):
+    def forward(ctx, x, w, stride, padding):
         N, C, H, W = x.shape
-        K = w.shape[0]
-        OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
-        w2 = w.reshape(K, C)
+        K, _, KH, KW = w.shape
+        OH = (H + 2 * padding - KH) // stride + 1
+        OW = (W + 2 * padding - KW) // stride + 1
         y = torch.empty((N, OH, OW, K), dtype=x.dtype, device=x.device)
-        ex = _gemm.pixel_map(_gemm.MAP_A, (OH, OW), (H, W), stride) if stride != 1 else None
-        _gemm.gemm_raw(_gemm.NT, x, w2, y, N * OH * OW, K, C, C, C, K, extra=ex)
-        ctx.save_for_backward(x, w2)
-        ctx.dims = (N, C, H, W, K, OH, OW, stride)
+        M = N * OH * OW
+        if KH == 1 and KW == 1 and stride == 1 and padding == 0:
+            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, C, C, C, K)
+        else:
+            ex = _gemm.conv_geom(_gemm.CONV_FWD, H, W, OH, OW, stride, padding, KH, KW, C, K)
+            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, KH * KW * C, C, KH * KW * C, K, extra=ex)
+        ctx.save_for_backward(x, w)
+        ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, stride, padding)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
-        x, w2 = ctx.saved_tensors
-        N, C, H, W, K, OH, OW, stride = ctx.dims
+        x, w = ctx.saved_tensors
+        N, C, H, W, K, KH, KW, OH, OW, stride, padding = ctx.geom
         if not gy.is_contiguous(memory_format=torch.channels_last):
             gy = gy.contiguous(memory_format=torch.channels_last)
-        M = N * OH * OW
+        plain = KH == 1 and KW == 1 and stride == 1 and padding == 0
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            if stride != 1:
-                gx = torch.zeros((N, H, W, C), dtype=x.dtype, device=x.device)
-                ex = _gemm.pixel_map(_gemm.MAP_C, (OH, OW), (H, W), stride)
+            gx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+            if plain:
+                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, K, K, C, C)
             else:
-                gx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
-                ex = None
-            _gemm.gemm_raw(_gemm.NN, gy, w2, gx, M, C, K, K, C, C, extra=ex)
+                ex = _gemm.conv_geom(_gemm.CONV_DGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K)
+                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, KH * KW * K, K, KH * KW * C, C, extra=ex)
             gx = gx.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            gw = torch.empty((K, C), dtype=w2.dtype, device=x.device)
-            ex = _gemm.pixel_map(_gemm.MAP_B, (OH, OW), (H, W), stride) if stride != 1 else None
-            _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, M, K, C, C, extra=ex)
-            gw = gw.view(K, 1, 1, C).permute(0, 3, 1, 2)   # [K, C, 1, 1], channels_last
-        return gx, gw, None
+            gw = torch.empty((K, KH, KW, C), dtype=w.dtype, device=x.device)
+            if plain:
+                _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, C)
+            else:
+                ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K)
+                _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex)
+            gw = gw.permute(0, 3, 1, 2)        # [K, C, KH, KW] with channels_last strides
+        return gx, gw, None, None
 
 
 def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.shape[1] % 8 == 0
-            and w.shape[0] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last))
+            and w.shape[0] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and w.is_contiguous(memory_format=torch.channels_last)
+            and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24))
 
 
 def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
     """Bias-free convolution of a channels_last activation with an ``[O, I, kh, kw]`` weight."""
-    if w.shape[2] == 1 and w.shape[3] == 1 and padding == 0 and _backend == "gemm" and _gemm_ok(x, w):
-        return _Conv1x1Fn.apply(x, w, stride)
+    one = w.shape[2] == 1 and w.shape[3] == 1
+    backend = _backend if one else _backend_kxk
+    if backend == "gemm" and stride in (1, 2) and _gemm_ok(x, w):
+        return _ConvFn.apply(x, w, stride, padding)
     if x.dtype != w.dtype:
         x = x.to(w.dtype)
     return F.conv2d(x, w, None, stride, padding)

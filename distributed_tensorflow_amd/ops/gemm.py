@@ -38,25 +38,28 @@ def supported(x: torch.Tensor, w: torch.Tensor) -> bool:
 
 
 class GemmExtra(ctypes.Structure):
-    """Mirror of the kernel's ``GemmExtra``: batch dims/strides and the strided-pixel row map."""
+    """Mirror of the kernel's ``GemmExtra``: batch dims/strides, convolution geometry, accumulate input."""
     _fields_ = [("nb1", ctypes.c_int), ("nb2", ctypes.c_int),
                 ("sA1", ctypes.c_longlong), ("sA2", ctypes.c_longlong), ("sB1", ctypes.c_longlong),
                 ("sB2", ctypes.c_longlong), ("sC1", ctypes.c_longlong), ("sC2", ctypes.c_longlong),
-                ("map_mask", ctypes.c_int), ("mOW", ctypes.c_int), ("mOH", ctypes.c_int), ("mW", ctypes.c_int),
-                ("mH", ctypes.c_int), ("mS", ctypes.c_int)]
+                ("conv", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("OH", ctypes.c_int),
+                ("OW", ctypes.c_int), ("S", ctypes.c_int), ("P", ctypes.c_int), ("KH", ctypes.c_int),
+                ("KW", ctypes.c_int), ("CI", ctypes.c_int), ("CO", ctypes.c_int), ("Cin", ctypes.c_void_p)]
 
 
-MAP_A, MAP_B, MAP_C = 1, 2, 4
+CONV_FWD, CONV_DGRAD, CONV_WGRAD = 1, 2, 3
 
 
-def pixel_map(mask: int, out_hw: tuple[int, int], in_hw: tuple[int, int], stride: int) -> GemmExtra:
-    """Row map of a strided 1x1 convolution: GEMM row (n, oh, ow) <-> memory row (n, oh*stride, ow*stride)."""
+def conv_geom(mode: int, H: int, W: int, OH: int, OW: int, stride: int, pad: int, KH: int, KW: int, CI: int,
+              CO: int) -> GemmExtra:
+    """Geometry of an NHWC convolution for the implicit-GEMM modes of the kernel."""
     ex = GemmExtra()
     ex.nb1 = ex.nb2 = 1
-    ex.map_mask = mask
-    ex.mOH, ex.mOW = out_hw
-    ex.mH, ex.mW = in_hw
-    ex.mS = stride
+    ex.conv = mode
+    ex.H, ex.W, ex.OH, ex.OW, ex.S, ex.P, ex.KH, ex.KW, ex.CI, ex.CO = H, W, OH, OW, stride, pad, KH, KW, CI, CO
+    if mode == CONV_WGRAD:       # one launch plane per filter tap; tap t writes columns [t*CI, (t+1)*CI) of dW
+        ex.nb2 = KH * KW
+        ex.sC2 = CI
     return ex
 
 
@@ -83,11 +86,12 @@ def _workspace(device, numel: int) -> torch.Tensor:
 
 
 def _pick_splits(M: int, N: int, K: int) -> int:
+    """Split-K factor: enough blocks for ~3 per CU, at least 8 k-tiles (512 deep) per split."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= _N_CU or K <= 512:
+    if tiles >= _N_CU or K <= 1024:
         return 1
-    want = max(1, (2 * _N_CU) // tiles)
-    return max(1, min(want, K // 256, 64))
+    want = -(-3 * _N_CU // tiles)
+    return max(1, min(want, K // 512, 512))
 
 
 def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, splits, out=None, extra=None,
@@ -101,11 +105,14 @@ def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, s
             raise ValueError("gemm output must be row-major")
     if N % 8 or ldc % 8 or out.data_ptr() % 16:
         raise ValueError("gemm output needs N % 8 == 0 and a 16-byte aligned row-major buffer")
-    if extra is not None and (extra.nb1 * extra.nb2 > 1 or extra.map_mask & MAP_C):
-        splits = 1
+    batch = 1
+    if extra is not None:
+        batch = max(1, extra.nb1) * max(1, extra.nb2)
+        if extra.Cin or (batch > 1 and extra.conv != CONV_WGRAD):
+            splits = 1
     if splits is None:
-        splits = _pick_splits(M, N, K)
-    ws = _workspace(dev, splits * M * N) if splits > 1 else None
+        splits = _pick_splits(M * batch if batch > 1 else M, N, K)
+    ws = _workspace(dev, splits * batch * M * N) if splits > 1 else None
     bias_dtype = 0
     if bias is not None:
         if bias.numel() != N or not bias.is_contiguous():
@@ -146,12 +153,21 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=N
 
 
 def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int,
-             ldb: int, ldc: int, extra: GemmExtra | None = None, bias=None, activation=None, splits=None):
+             ldb: int, ldc: int, extra: GemmExtra | None = None, bias=None, activation=None, splits=None,
+             add: torch.Tensor | None = None):
     """Unchecked launch on explicit dimensions and leading dimensions (batched attention products,
-    strided 1x1 convolutions). The caller guarantees 16-byte alignment of every row it addresses."""
+    implicit-GEMM convolutions). ``add`` is a bf16 tensor laid out like ``out`` that is added to the
+    result in the epilogue. The caller guarantees 16-byte alignment of every row it addresses."""
     for t in (A, B, out):
         if t.data_ptr() % 16:
             raise ValueError("gemm_raw: operands must be 16-byte aligned")
+    if add is not None:
+        if add.data_ptr() % 16 or add.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
+            raise ValueError("gemm_raw: add= needs 16-byte aligned bf16 tensors")
+        if extra is None:
+            extra = GemmExtra()
+            extra.nb1 = extra.nb2 = 1
+        extra.Cin = add.data_ptr()
     if lda % 8 or ldb % 8 or ldc % 8:
         raise ValueError("gemm_raw: leading dimensions must be multiples of 8 elements")
     return _launch(layout, A, B, M, N, K, lda, ldb, bias, activation, out.dtype, splits, out=out, extra=extra, ldc=ldc)

@@ -49,9 +49,10 @@ class _BNActFn(torch.autograd.Function):
                                   _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), ctypes.c_longlong(M), C,
                                   ctypes.c_float(eps), ctypes.c_float(momentum), int(relu), _lib.stream_ptr(dev))
         _lib.check(rc, "bn_fwd_train")
-        ctx.relu = bool(relu)
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, y if relu else None, gamma, stats)
+        # relu mask: from the saved output when a residual took part, else recomputed from x (y is not kept)
+        ctx.relu = 0 if not relu else (1 if residual is not None else 2)
+        ctx.save_for_backward(x, y if ctx.relu == 1 else None, gamma, stats)
         return y
 
     @staticmethod
@@ -63,7 +64,7 @@ class _BNActFn(torch.autograd.Function):
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
-        need_dres = ctx.has_res and ctx.relu
+        need_dres = ctx.has_res and ctx.relu != 0
         dres = torch.empty_like(x) if need_dres else None
         dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
         coef = torch.empty(3, C, dtype=torch.float32, device=dev)
@@ -71,10 +72,11 @@ class _BNActFn(torch.autograd.Function):
         nb = lib.dtf_bn_num_partials(ctypes.c_longlong(M), C)
         ws = _scratch(dev, nb * 2 * C)
         rc = lib.dtf_bn_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(stats[0]),
-                            _lib.ptr(stats[1]), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]),
-                            _lib.ptr(coef), _lib.ptr(ws), ctypes.c_longlong(M), C, int(ctx.relu), _lib.stream_ptr(dev))
+                            _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(dx), _lib.ptr(dres),
+                            _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(coef), _lib.ptr(ws), ctypes.c_longlong(M), C,
+                            int(ctx.relu), _lib.stream_ptr(dev))
         _lib.check(rc, "bn_bwd")
-        if ctx.has_res and not ctx.relu:
+        if ctx.has_res and ctx.relu == 0:
             dres = dy
         return dx, dgb[0], dgb[1], None, None, None, None, None, dres
 

@@ -252,23 +252,47 @@ def test_batch_norm_act_matches_torch(N, C, H, W, relu, use_res):
     torch.testing.assert_close(ye.float(), yer, rtol=2e-2, atol=3e-2)
 
 
-@pytest.mark.parametrize("stride", [1, 2])
-def test_conv1x1_gemm_matches_library(stride):
+@pytest.mark.parametrize("cfg", [
+    # (N, C, H, W, K, k, stride, pad)
+    (4, 64, 14, 14, 256, 1, 1, 0), (4, 64, 14, 14, 256, 1, 2, 0), (3, 64, 15, 13, 64, 3, 1, 1),
+    (2, 128, 28, 28, 128, 3, 2, 1), (2, 8, 33, 31, 64, 7, 2, 3), (5, 256, 7, 7, 512, 3, 1, 1),
+    (2, 16, 32, 32, 32, 3, 2, 1), (1, 512, 9, 9, 24, 3, 1, 0),
+])
+def test_implicit_gemm_conv_matches_library(cfg):
     from distributed_tensorflow_amd.ops import conv
-    torch.manual_seed(3)
-    x = torch.randn(4, 64, 14, 14, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(256, 64, 1, 1, device=DEV) * 0.1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    N, C, H, W, K, k, stride, pad = cfg
+    torch.manual_seed(sum(cfg))
+    x = torch.randn(N, C, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(K, C, k, k, device=DEV) * (1.0 / math.sqrt(C * k * k))).to(torch.bfloat16)
+    w = w.contiguous(memory_format=torch.channels_last)
     outs = {}
     for be in ("gemm", "library"):
-        conv.set_conv1x1_backend(be)
+        conv.set_conv1x1_backend(be); conv.set_convkxk_backend(be)
         x1 = x.clone().requires_grad_(True); w1 = w.clone().requires_grad_(True)
-        y = conv.conv2d(x1, w1, stride, 0)
+        y = conv.conv2d(x1, w1, stride, pad)
         dy = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).to(torch.bfloat16)
         y.backward(dy)
         outs[be] = (y.float(), x1.grad.float(), w1.grad.float())
-    conv.set_conv1x1_backend("gemm")
-    for a, b in zip(outs["gemm"], outs["library"]):
-        torch.testing.assert_close(a, b, rtol=3e-2, atol=1e-1)
+    conv.set_conv1x1_backend("gemm"); conv.set_convkxk_backend("gemm")
+    # fp32 reference for the tolerance scale
+    yr = torch.nn.functional.conv2d(x.float(), w.float(), None, stride, pad)
+    assert outs["gemm"][0].shape == yr.shape
+    torch.testing.assert_close(outs["gemm"][0], yr, rtol=2e-2, atol=3e-2)
+    for a, b, name in zip(outs["gemm"], outs["library"], ("y", "dx", "dw")):
+        scale = max(1.0, float(b.abs().max()))
+        torch.testing.assert_close(a / scale, b / scale, rtol=3e-2, atol=2e-2, msg=lambda m: name + ": " + m)
+
+
+def test_gemm_epilogue_accumulates_onto_existing_tensor():
+    from distributed_tensorflow_amd.ops import gemm
+    torch.manual_seed(0)
+    a = torch.randn(300, 64, device=DEV).to(torch.bfloat16)
+    b = torch.randn(64, 136, device=DEV).to(torch.bfloat16)       # [K, N]
+    base = torch.randn(300, 136, device=DEV).to(torch.bfloat16)
+    out = torch.empty_like(base)
+    gemm.gemm_raw(gemm.NN, a, b, out, 300, 136, 64, 64, 136, 136, add=base)
+    ref = ((a.float() @ b.float()).to(torch.bfloat16).float() + base.float()).to(torch.bfloat16)
+    torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=6e-2)
 
 
 def test_resnet_train_step_decreases_loss():
