@@ -63,6 +63,7 @@ constexpr int kTileBytes = BM * BK * 2;  // 16 KiB per operand tile
 // Convolution geometry (NHWC). x: [N][H][W][CI], dy / y: [N][OH][OW][CO], w: [CO][KH][KW][CI].
 struct ConvGeom {
   int H, W, OH, OW, S, P, KH, KW, CI, CO;
+  int NB;            // images in the batch (row order of the strided data gradient)
   float r_ohw, r_ow, r_hw, r_w, r_ci, r_co, r_kw;   // reciprocals for the exact float divmod below
 };
 
@@ -103,6 +104,30 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {
 // slots of the 256-byte bank row: conflict-free transposed reads.
 __device__ __forceinline__ int swz_t(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
 
+// Row order of the data-gradient GEMM. Stride 1: m = (n, ih, iw), the memory order. Stride 2: the
+// rows are grouped by the parity class (ih & 1, iw & 1) of the input pixel,
+//   m = ((class * N + n) * H/2 + ih/2) * W/2 + iw/2,
+// because a filter tap (kh, kw) reaches an input pixel only when ih + P - kh and iw + P - kw are
+// even: inside one class the set of contributing taps is the same for every row, so a tile that
+// lies in one class skips the k-tiles of the other taps (3/4 of them for a 3x3 filter, all of them
+// for three of the four classes of a strided 1x1). H and W must be even for stride 2.
+__device__ __forceinline__ void dgrad_pixel(const ConvGeom& c, int m, int& n, int& ih, int& iw) {
+  int rem;
+  if (c.S == 1) {
+    divmod(m, c.H * c.W, c.r_hw, n, rem);
+    divmod(rem, c.W, c.r_w, ih, iw);
+  } else {
+    const int h2 = c.H >> 1, w2 = c.W >> 1;
+    int q, a, b;
+    divmod(m, h2 * w2, 4.f * c.r_hw, q, rem);         // q = class * N + n
+    divmod(rem, w2, 2.f * c.r_w, a, b);
+    const int cls = q / c.NB;
+    n = q - cls * c.NB;
+    ih = 2 * a + (cls >> 1);
+    iw = 2 * b + (cls & 1);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Operand stagers. Each thread owns 4 x 16-byte chunks of a tile. Per-row geometry that does not
 // depend on the k-tile is computed once in init() and kept in registers.
@@ -117,8 +142,10 @@ struct Stager {
   int base[4];       // pixel index base (GATHER 1, 2)
   int ca[4], cb[4];  // ih0 / iw0 (GATHER 1) or ih+P / iw+P (GATHER 2)
   bool rowok[4];
+  int tkh, tkw;      // filter tap of this launch plane (GATHER 3)
 
-  __device__ __forceinline__ void init(const GemmArgs& g, int rows, int row0) {
+  __device__ __forceinline__ void init(const GemmArgs& g, int rows, int row0, int tap) {
+    if (GATHER == 3) divmod(tap, g.cv.KW, g.cv.r_kw, tkh, tkw);
     if (T == 0 && (GATHER == 1 || GATHER == 2)) {
       const ConvGeom& c = g.cv;
 #pragma unroll
@@ -132,9 +159,8 @@ struct Stager {
           divmod(rem, c.OW, c.r_ow, a, b);
           ca[i] = a * c.S - c.P; cb[i] = b * c.S - c.P;
           base[i] = (n * c.H + ca[i]) * c.W + cb[i];
-        } else {                            // m = (n, ih, iw)
-          divmod(m, c.H * c.W, c.r_hw, n, rem);
-          divmod(rem, c.W, c.r_w, a, b);
+        } else {                            // m = input pixel, see dgrad_pixel()
+          dgrad_pixel(c, m, n, a, b);
           ca[i] = a + c.P; cb[i] = b + c.P;
           base[i] = n * c.OH * c.OW;
         }
@@ -187,28 +213,33 @@ struct Stager {
       const int rc = threadIdx.x & 15, kg = threadIdx.x >> 4;
       const int row = row0 + (rc << 3);
       const bool rok = row < rows;
+      const int kf = k0 + kg * 4;           // this thread's first k of the tile; k = kf + i
+      // one divmod per tile; the following three k are reached by increment-with-carry
+      int t = 0, co = 0, n = 0, oh = 0, ow = 0;
+      if (GATHER == 4) divmod(kf < kend ? kf : 0, c.CO, c.r_co, t, co);
+      if (GATHER == 3) {
+        int rem;
+        divmod(kf < kend ? kf : 0, c.OH * c.OW, c.r_ohw, n, rem);
+        divmod(rem, c.OW, c.r_ow, oh, ow);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int k = k0 + kg * 4 + i;
+        const int k = kf + i;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (rok && k < kend) {
           if (GATHER == 0) {
             v = *reinterpret_cast<const u32x4*>(X + (long long)k * ld + row);
           } else if (GATHER == 4) {         // weights for dgrad: k = (tap, co) -> w[co][tap][ci = row]
-            int t, co;
-            divmod(k, c.CO, c.r_co, t, co);
             v = *reinterpret_cast<const u32x4*>(X + (long long)co * ld + t * c.CI + row);
           } else {                          // GATHER 3: k = output pixel, tap fixed: x[(n, oh*S+kh-P, ow*S+kw-P)][row]
-            int n, rem, oh, ow, kh, kw;
-            divmod(k, c.OH * c.OW, c.r_ohw, n, rem);
-            divmod(rem, c.OW, c.r_ow, oh, ow);
-            divmod(tap, c.KW, c.r_kw, kh, kw);
-            const int ih = oh * c.S + kh - c.P, iw = ow * c.S + kw - c.P;
+            const int ih = oh * c.S + tkh - c.P, iw = ow * c.S + tkw - c.P;
             if (ih >= 0 && ih < c.H && iw >= 0 && iw < c.W)
               v = *reinterpret_cast<const u32x4*>(X + (long long)((n * c.H + ih) * c.W + iw) * c.CI + row);
           }
         }
         r[i] = v;
+        if (GATHER == 4) { if (++co == c.CO) { co = 0; ++t; } }
+        if (GATHER == 3) { if (++ow == c.OW) { ow = 0; if (++oh == c.OH) { oh = 0; ++n; } } }
       }
     }
   }
@@ -259,18 +290,24 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 tiles: A0 B0 A1 B1 (64 KiB)
 
   // ---- block -> tile map: XCD-aware, bijective for any grid size --------------------
-  const int nwg = g.tiles_m * g.tiles_n;
+  // CONV 3 (weight gradient): the filter taps of one (tile, split) are neighbouring blocks of one XCD,
+  // so the dy tile they all read and the overlapping x pixels are served by that XCD's L2.
+  const int ntaps = CONV == 3 ? g.cv.KH * g.cv.KW : 1;
+  const int nwg = g.tiles_m * g.tiles_n * ntaps;
   const int orig = blockIdx.x;
   const int xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
-  const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+  const int vt = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+  const int tile = vt / ntaps;
+  const int tap = vt - tile * ntaps;
   const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int split = blockIdx.y;
-  const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z - b1 * g.nb2;
+  const int plane = CONV == 3 ? tap : (int)blockIdx.z;
+  const int planes = CONV == 3 ? ntaps : (int)gridDim.z;
+  const int b1 = plane / g.nb2, b2 = plane - b1 * g.nb2;
   const unsigned short* Ap = g.A + b1 * g.sA1 + b2 * g.sA2;
   const unsigned short* Bp = g.B + b1 * g.sB1 + b2 * g.sB2;
   const long long c_off = b1 * g.sC1 + b2 * g.sC2;
-  const int tap = blockIdx.z;            // CONV 3: one launch plane per filter tap
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nt = (kend - kbeg + BK - 1) / BK;
@@ -289,21 +326,47 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   constexpr int GB = CONV == 2 ? 4 : CONV == 3 ? 3 : 0;
   Stager<A_T, GA> sa;
   Stager<B_T, GB> sb;
-  sa.init(g, g.M, m0);
-  sb.init(g, g.N, n0);
-  if (nt > 0) {
-    sa.load(g, Ap, g.lda, g.M, m0, kbeg, kend, tap);
-    sb.load(g, Bp, g.ldb, g.N, n0, kbeg, kend, tap);
+  sa.init(g, g.M, m0, tap);
+  sb.init(g, g.N, n0, tap);
+
+  // Strided data gradient: when the whole tile lies in one parity class, k-tiles whose filter tap
+  // cannot reach that class are skipped (they would multiply zeros). skip_par = class parities + P.
+  bool can_skip = false;
+  int par_h = 0, par_w = 0;
+  if (CONV == 2 && g.cv.S == 2 && (g.cv.CO % BK) == 0) {
+    const int per_class = g.cv.NB * (g.cv.H >> 1) * (g.cv.W >> 1);
+    const int c_lo = m0 / per_class, c_hi = min(m0 + BM - 1, g.M - 1) / per_class;
+    can_skip = c_lo == c_hi;
+    par_h = ((c_lo >> 1) + g.cv.P) & 1;
+    par_w = ((c_lo & 1) + g.cv.P) & 1;
+  }
+  auto next_tile = [&](int t) -> int {     // first k-tile index >= t that contributes
+    if (CONV == 2) {
+      while (can_skip && t < nt) {
+        const int tp = (kbeg + t * BK) / g.cv.CO;
+        const int kh = tp / g.cv.KW, kw = tp - kh * g.cv.KW;
+        if (((kh & 1) == par_h) && ((kw & 1) == par_w)) break;
+        ++t;
+      }
+    }
+    return t;
+  };
+
+  int t = next_tile(0);
+  if (t < nt) {
+    sa.load(g, Ap, g.lda, g.M, m0, kbeg + t * BK, kend, tap);
+    sb.load(g, Bp, g.ldb, g.N, n0, kbeg + t * BK, kend, tap);
     sa.store(smem);
     sb.store(smem + kTileBytes);
   }
   __syncthreads();
 
   int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    const bool more = (t + 1) < nt;
+  while (t < nt) {
+    const int tnext = next_tile(t + 1);
+    const bool more = tnext < nt;
     if (more) {
-      const int k0 = kbeg + (t + 1) * BK;
+      const int k0 = kbeg + tnext * BK;
       sa.load(g, Ap, g.lda, g.M, m0, k0, kend, tap);
       sb.load(g, Bp, g.ldb, g.N, n0, k0, kend, tap);
     }
@@ -330,13 +393,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
     __syncthreads();
     cur ^= 1;
+    t = tnext;
   }
 
   // ---- epilogue ---------------------------------------------------------------------
   const int wm0 = m0 + wm * 64, wn0 = n0 + wn * 64;
   if (g.splits > 1) {
     // fp32 partial slab [split][batch][M][N]; 16 bytes per lane, 4 consecutive n
-    float* W = reinterpret_cast<float*>(g.C) + ((long long)split * gridDim.z + blockIdx.z) * g.M * g.N;
+    float* W = reinterpret_cast<float*>(g.C) + ((long long)split * planes + plane) * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = wm0 + i * 16 + fr;
@@ -415,9 +479,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     const int m = wm0 + row, n = wn0 + chunk * 8;
     u32x4 v = *reinterpret_cast<const u32x4*>(stage + swz_off(row, chunk));
     if (m < g.M && n < g.N) {
+      long long mr = m;
+      if (CONV == 2 && g.cv.S == 2) {       // class-ordered GEMM row -> pixel row in memory
+        int pn, ph, pw;
+        dgrad_pixel(g.cv, m, pn, ph, pw);
+        mr = ((long long)pn * g.cv.H + ph) * g.cv.W + pw;
+      }
       if (Cin) {
         // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
-        const u32x4 c = *reinterpret_cast<const u32x4*>(Cin + (long long)m * g.ldc + n);
+        const u32x4 c = *reinterpret_cast<const u32x4*>(Cin + mr * g.ldc + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float lo = __uint_as_float(v[e] << 16) + __uint_as_float(c[e] << 16);
@@ -425,7 +495,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
           v[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
         }
       }
-      *reinterpret_cast<u32x4*>(C + (long long)m * g.ldc + n) = v;
+      *reinterpret_cast<u32x4*>(C + mr * g.ldc + n) = v;
     }
   }
 }
@@ -496,7 +566,7 @@ struct GemmExtra {
   int nb1, nb2;                      // batch = nb1 * nb2 (0 or 1 = not batched)
   long long sA1, sA2, sB1, sB2, sC1, sC2;
   int conv;                          // 0 plain, 1 conv forward, 2 conv dgrad, 3 conv wgrad
-  int H, W, OH, OW, S, P, KH, KW, CI, CO;
+  int H, W, OH, OW, S, P, KH, KW, CI, CO, NB;
   const void* Cin;                   // optional bf16 tensor added to the output
 };
 
@@ -513,7 +583,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   int batch = 1, conv = 0;
   g.nb2 = 1; g.sA1 = g.sA2 = g.sB1 = g.sB2 = g.sC1 = g.sC2 = 0;
   ConvGeom& c = g.cv;
-  c.H = c.W = c.OH = c.OW = c.S = c.KH = c.KW = c.CI = c.CO = 1; c.P = 0;
+  c.H = c.W = c.OH = c.OW = c.S = c.KH = c.KW = c.CI = c.CO = c.NB = 1; c.P = 0;
   if (ex) {
     const int nb1 = ex->nb1 > 0 ? ex->nb1 : 1;
     g.nb2 = ex->nb2 > 0 ? ex->nb2 : 1;
@@ -523,8 +593,10 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
     conv = ex->conv;
     if (conv) {
       c.H = ex->H; c.W = ex->W; c.OH = ex->OH; c.OW = ex->OW; c.S = ex->S; c.P = ex->P; c.KH = ex->KH; c.KW = ex->KW;
-      c.CI = ex->CI; c.CO = ex->CO;
+      c.CI = ex->CI; c.CO = ex->CO; c.NB = ex->NB > 0 ? ex->NB : 1;
       if (c.S != 1 && c.S != 2) return -4;
+      if (conv == 2 && c.S == 2 && ((c.H | c.W) & 1)) return -7;   // class-ordered rows need even H, W
+      if (conv == 2 && out_fp32) return -6;
       if ((long long)M >= (1 << 24) || (long long)K >= (1 << 24)) return -5;   // float divmod range
     }
   }
@@ -532,12 +604,14 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   c.r_w = 1.f / (float)c.W; c.r_ci = 1.f / (float)c.CI; c.r_co = 1.f / (float)c.CO; c.r_kw = 1.f / (float)c.KW;
   if (g.Cin && out_fp32) return -6;
   if (g.Cin || (batch > 1 && conv != 3)) splits = 1;   // slabs carry neither C_in nor strided batches
+  if (conv == 2 && c.S == 2) splits = 1;               // nor the class-ordered row map of a strided dgrad
   int kps = ((K + splits - 1) / splits + BK - 1) / BK * BK;
   splits = (K + kps - 1) / kps;
   g.k_per_split = kps; g.splits = splits;
   g.C = splits > 1 ? workspace : C;
   if (splits > 1 && !workspace) return -3;
-  const dim3 grid(g.tiles_m * g.tiles_n, splits, batch);
+  // the taps of a weight-gradient launch are folded into grid.x (see the kernel's tile map)
+  const dim3 grid(g.tiles_m * g.tiles_n * (conv == 3 ? batch : 1), splits, conv == 3 ? 1 : batch);
   const size_t lds = 4 * kTileBytes;
 #define GEMM_LAUNCH(AT, BT, CV) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV>), grid, dim3(kThreads), lds, stream, g)
   if (conv == 0) {

@@ -65,7 +65,7 @@ class _ConvFn(torch.autograd.Function):
         if KH == 1 and KW == 1 and stride == 1 and padding == 0:
             _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, C, C, C, K)
         else:
-            ex = _gemm.conv_geom(_gemm.CONV_FWD, H, W, OH, OW, stride, padding, KH, KW, C, K)
+            ex = _gemm.conv_geom(_gemm.CONV_FWD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
             _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, KH * KW * C, C, KH * KW * C, K, extra=ex)
         ctx.save_for_backward(x, w)
         ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, stride, padding)
@@ -84,7 +84,7 @@ class _ConvFn(torch.autograd.Function):
             if plain:
                 _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, K, K, C, C)
             else:
-                ex = _gemm.conv_geom(_gemm.CONV_DGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K)
+                ex = _gemm.conv_geom(_gemm.CONV_DGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, KH * KW * K, K, KH * KW * C, C, extra=ex)
             gx = gx.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
@@ -92,7 +92,7 @@ class _ConvFn(torch.autograd.Function):
             if plain:
                 _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, C)
             else:
-                ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K)
+                ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex)
             gw = gw.permute(0, 3, 1, 2)        # [K, C, KH, KW] with channels_last strides
         return gx, gw, None, None
@@ -109,7 +109,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0) 
     """Bias-free convolution of a channels_last activation with an ``[O, I, kh, kw]`` weight."""
     one = w.shape[2] == 1 and w.shape[3] == 1
     backend = _backend if one else _backend_kxk
-    if backend == "gemm" and stride in (1, 2) and _gemm_ok(x, w):
+    if backend == "gemm" and stride in (1, 2) and _gemm_ok(x, w) and (stride == 1 or (x.shape[2] % 2 == 0 and
+                                                                                 x.shape[3] % 2 == 0)):
         return _ConvFn.apply(x, w, stride, padding)
     if x.dtype != w.dtype:
         x = x.to(w.dtype)

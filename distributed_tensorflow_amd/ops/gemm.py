@@ -44,18 +44,20 @@ class GemmExtra(ctypes.Structure):
                 ("sB2", ctypes.c_longlong), ("sC1", ctypes.c_longlong), ("sC2", ctypes.c_longlong),
                 ("conv", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("OH", ctypes.c_int),
                 ("OW", ctypes.c_int), ("S", ctypes.c_int), ("P", ctypes.c_int), ("KH", ctypes.c_int),
-                ("KW", ctypes.c_int), ("CI", ctypes.c_int), ("CO", ctypes.c_int), ("Cin", ctypes.c_void_p)]
+                ("KW", ctypes.c_int), ("CI", ctypes.c_int), ("CO", ctypes.c_int), ("NB", ctypes.c_int),
+                ("Cin", ctypes.c_void_p)]
 
 
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 1, 2, 3
 
 
 def conv_geom(mode: int, H: int, W: int, OH: int, OW: int, stride: int, pad: int, KH: int, KW: int, CI: int,
-              CO: int) -> GemmExtra:
-    """Geometry of an NHWC convolution for the implicit-GEMM modes of the kernel."""
+              CO: int, NB: int = 1) -> GemmExtra:
+    """Geometry of an NHWC convolution for the implicit-GEMM modes of the kernel (``NB`` images)."""
     ex = GemmExtra()
     ex.nb1 = ex.nb2 = 1
     ex.conv = mode
+    ex.NB = NB
     ex.H, ex.W, ex.OH, ex.OW, ex.S, ex.P, ex.KH, ex.KW, ex.CI, ex.CO = H, W, OH, OW, stride, pad, KH, KW, CI, CO
     if mode == CONV_WGRAD:       # one launch plane per filter tap; tap t writes columns [t*CI, (t+1)*CI) of dW
         ex.nb2 = KH * KW
@@ -108,7 +110,7 @@ def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, s
     batch = 1
     if extra is not None:
         batch = max(1, extra.nb1) * max(1, extra.nb2)
-        if extra.Cin or (batch > 1 and extra.conv != CONV_WGRAD):
+        if extra.Cin or (batch > 1 and extra.conv != CONV_WGRAD) or (extra.conv == CONV_DGRAD and extra.S == 2):
             splits = 1
     if splits is None:
         splits = _pick_splits(M * batch if batch > 1 else M, N, K)
