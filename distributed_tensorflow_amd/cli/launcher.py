@@ -76,7 +76,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="default: sum for centralized (reference semantics), mean for decentralized")
     p.add_argument("--placement", choices=["colocated", "dedicated"], default="colocated",
                    help="async collective PS: shard owners are the workers | one extra server rank")
-    p.add_argument("--algorithm", default="auto", help="custom strategy: auto|direct|ring|multiring|tree|oneshot")
+    p.add_argument("--algorithm", default="auto", help="custom strategy: auto|direct|ring|multiring|tree|oneshot on grouped send/recv, or "
+                   "ipc|ipc-direct|ipc-oneshot|ipc-ring|ipc-tree: kernels on HIP IPC mapped peer arenas")
     p.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
     p.add_argument("--port", type=int, default=6000, help="parameter-server / rendezvous port")
     p.add_argument("--metrics", default=None, help="JSONL metrics path (%%r = rank)")

@@ -35,7 +35,10 @@ class Comm:
         if world == 1:
             return cls(0, 1, device)
         if backend is None:
-            backend = "nccl" if device.type == "cuda" else "gloo"
+            backend = os.environ.get("DTF_COMM") or ("nccl" if device.type == "cuda" else "gloo")
+        if backend == "rccl":       # the framework's own RCCL binding instead of torch.distributed
+            from .rccl import RcclComm
+            return RcclComm.create(rank, world, device, master_addr, master_port, timeout_s)
         if not dist.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             kw = {}

@@ -70,20 +70,36 @@ class CustomAllReduceStrategy(Strategy):
         self.broadcast_initial(0)
         self._scale = 1.0 / comm.world if self.cfg.loss_reduction == "mean" else 1.0
         biggest = max(b.numel for b in self.planner.buckets)
-        self._scratch = torch.empty(biggest, dtype=self.flat.grad.dtype, device=comm.device) if comm.world > 1 else None
         self.used_algorithms: list[str] = []
+        # 'ipc' / 'ipc-<schedule>': kernels on HIP IPC mapped peer arenas instead of grouped send/recv
+        self._peers = None
+        self._scratch = None
+        if algorithm.startswith("ipc") and comm.world > 1:
+            if comm.device.type != "cuda":
+                raise ValueError("the peer-pointer algorithms need GPU devices")
+            from ..comm.ipc import PeerGroup
+            self._peers = PeerGroup(comm)
+            self._peers.register(self.flat.grad)
+            self._ipc_schedule = algorithm.partition("-")[2] or "auto"
+        elif comm.world > 1:
+            self._scratch = torch.empty(biggest, dtype=self.flat.grad.dtype, device=comm.device)
+
+    def _reduce(self, view):
+        if self._peers is not None:
+            return "ipc-" + self._peers.all_reduce(view, self._ipc_schedule, base=self.flat.grad)
+        return algos.all_reduce(self.comm, view, self.algorithm, self._scratch)
 
     def _on_ready(self, b):
         view = self.flat.grad[b.start:b.end]
         side = self.side_stream()
         if side is None:
-            self.used_algorithms.append(algos.all_reduce(self.comm, view, self.algorithm, self._scratch))
+            self.used_algorithms.append(self._reduce(view))
             return None
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            self.used_algorithms.append(algos.all_reduce(self.comm, view, self.algorithm, self._scratch))
+            self.used_algorithms.append(self._reduce(view))
             done = torch.cuda.Event()
             done.record(side)
         return done

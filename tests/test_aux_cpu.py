@@ -162,3 +162,37 @@ def test_native_loader_gathers_and_normalises():
         assert by.tolist() == y[i].tolist()
         ld.release(s)
     ld.close()
+
+
+# ------------------------------------------------------------------ peer-pointer schedules
+@pytest.mark.parametrize("algorithm", ["direct", "oneshot", "ring", "tree"])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 7, 8])
+def test_peer_pointer_schedule_emulation(algorithm, world):
+    """Every rank ends with scale * sum, and no phase reads what another rank writes."""
+    from distributed_tensorflow_amd.comm import ipc
+
+    torch.manual_seed(world)
+    for n in (5, 64, 1003):
+        bufs = [torch.randn(n, dtype=torch.float32) for _ in range(world)]
+        want = sum(b.double() for b in bufs) * 0.5
+        ipc.emulate(algorithm, bufs, scale=0.5)
+        for r, b in enumerate(bufs):
+            assert torch.allclose(b.double(), want, atol=1e-5), (algorithm, world, n, r)
+
+
+def test_peer_pointer_emulator_detects_races():
+    from distributed_tensorflow_amd.comm import ipc
+
+    real_plan = ipc.plan
+
+    def racy(algorithm, rank, world, n, esz, scale=1.0):
+        # a "direct" schedule without the barrier between reduce-scatter and all-gather
+        ph = real_plan("direct", rank, world, n, esz, scale)
+        return [ph[0] + ph[1]]
+
+    ipc.plan = racy
+    try:
+        with pytest.raises(AssertionError):
+            ipc.emulate("direct", [torch.randn(64) for _ in range(4)])
+    finally:
+        ipc.plan = real_plan

@@ -1,0 +1,146 @@
+"""GPU tests of the native communication layer on ONE device: the RCCL binding at world size 1,
+the peer-pointer kernels with virtual ranks, and the HIP-IPC peer group with several processes
+that share the GPU (kernel logic, flags and schedules are exercised without xGMI)."""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+# ----------------------------------------------------------------------------- RCCL binding
+def test_rccl_binding_world1_collectives():
+    from distributed_tensorflow_amd.comm.rccl import RcclComm, _rt
+
+    assert _rt().dtf_rccl_version() > 0
+    comm = RcclComm.create(0, 1, _dev())
+    try:
+        x = torch.randn(1 << 20, device=_dev())
+        ref = x.clone()
+        w = comm.all_reduce(x, async_op=True)
+        w.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+        xb = torch.randn(4096, device=_dev()).bfloat16()
+        refb = xb.clone()
+        comm.all_reduce(xb)
+        out = torch.empty_like(xb)
+        comm.reduce_scatter(out, xb)
+        comm.all_gather(xb, out)
+        comm.broadcast(xb, 0)
+        comm.reduce(xb, 0)
+        a2a = torch.empty_like(xb)
+        comm.all_to_all(a2a, xb)
+        torch.cuda.synchronize()
+        assert torch.equal(xb, refb) and torch.equal(out, refb) and torch.equal(a2a, refb)
+        comm.barrier()
+        comm.check_async_error()
+        assert comm.all_reduce_scalar(3.0) == 3.0
+    finally:
+        comm.shutdown()
+
+
+# ------------------------------------------------------------------- kernels, virtual ranks
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("algorithm", ["direct", "oneshot", "ring", "tree"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_peer_pointer_kernels_virtual_ranks(algorithm, world, dtype):
+    from distributed_tensorflow_amd.comm.ipc import LocalPeers
+
+    torch.manual_seed(world)
+    for n in (8, 1000, 262147):
+        bufs = [torch.randn(n, device=_dev()).to(dtype) for _ in range(world)]
+        want = sum(b.double() for b in bufs) * 0.25
+        LocalPeers(bufs).all_reduce(algorithm, scale=0.25)
+        torch.cuda.synchronize()
+        tol = 1e-5 if dtype == torch.float32 else 0.05 * world ** 0.5
+        for r, b in enumerate(bufs):
+            assert torch.allclose(b.double(), want, atol=tol, rtol=1e-2 if dtype == torch.bfloat16 else 1e-5), \
+                (algorithm, world, n, r, float((b.double() - want).abs().max()))
+        if algorithm in ("direct", "oneshot"):   # fixed summation order: every rank holds the same bits
+            for b in bufs[1:]:
+                assert torch.equal(b, bufs[0])
+
+
+def test_peer_pointer_region_of_a_larger_buffer():
+    from distributed_tensorflow_amd.comm.ipc import LocalPeers
+
+    world, n = 4, 5000
+    bufs = [torch.randn(n, device=_dev()) for _ in range(world)]
+    keep = [b.clone() for b in bufs]
+    want = sum(b[1024:1024 + 3001].double() for b in bufs)
+    LocalPeers(bufs).all_reduce("direct", start=1024, numel=3001)
+    torch.cuda.synchronize()
+    for b, k in zip(bufs, keep):
+        assert torch.allclose(b[1024:4025].double(), want, atol=1e-5)
+        assert torch.equal(b[:1024], k[:1024]) and torch.equal(b[4025:], k[4025:])
+
+
+# ----------------------------------------------------------- several processes, one device
+def _ipc_worker(rank, world, port, q):
+    try:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        from distributed_tensorflow_amd.comm.backend import Comm
+        from distributed_tensorflow_amd.comm.ipc import PeerGroup
+
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        comm = Comm.init(rank, world, dev, master_port=port, timeout_s=60, backend="gloo")
+        pg = PeerGroup(comm, barrier_budget_ms=10000)
+        torch.manual_seed(100 + rank)
+        arena = torch.randn(300000, device=dev)
+        mine = arena.clone()
+        pg.register(arena)
+        res = {}
+        for alg, lo, n in (("direct", 0, 300000), ("oneshot", 1024, 4099), ("ring", 8192, 100003),
+                           ("tree", 0, 777), ("auto", 2048, 262144)):
+            arena.copy_(mine)
+            torch.cuda.synchronize()
+            pg.all_reduce(arena[lo:lo + n], alg, scale=1.0 / world, base=arena)
+            pg.check()
+            # reference through gloo on the host
+            ref = mine[lo:lo + n].cpu()
+            torch.distributed.all_reduce(ref)
+            ref /= world
+            res[alg] = float((arena[lo:lo + n].cpu() - ref).abs().max())
+            outside = torch.equal(arena[:lo], mine[:lo]) and torch.equal(arena[lo + n:], mine[lo + n:])
+            res[alg + "_outside_untouched"] = bool(outside)
+        pg.close()
+        comm.shutdown()
+        q.put((rank, res))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, {"error": f"{e}\n{traceback.format_exc()}"}))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_group_processes_sharing_one_gpu(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + world
+    procs = [ctx.Process(target=_ipc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r, res = q.get(timeout=100)
+            got[r] = res
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+    for r, res in got.items():
+        assert "error" not in res, res.get("error")
+        for k, v in res.items():
+            if k.endswith("_outside_untouched"):
+                assert v, (r, k)
+            else:
+                assert v < 1e-5, (r, k, v)
