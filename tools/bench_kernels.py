@@ -115,6 +115,22 @@ def main():
         print(f"gemm {M}x{N}x{Kd}: " + " ".join(f"{k}={v:.1f}" for k, v in r.items() if k.endswith("TF")), flush=True)
         del A, Bm, Bt, G
 
+    # ---- peer-pointer collective kernels on one device (virtual ranks: "peers" are local buffers),
+    #      bytes = what one rank's kernels read + write for a full all-reduce
+    from distributed_tensorflow_amd.comm.ipc import LocalPeers
+    for world, n, dt in [(8, 25_600_000, torch.bfloat16), (8, 25_600_000, torch.float32), (8, 65536, torch.float32)]:
+        bufs = [torch.randn(n, device=DEV).to(dt) for _ in range(world)]
+        lp = LocalPeers(bufs)
+        esz = bufs[0].element_size()
+        for alg in ("direct", "oneshot", "ring"):
+            t = timeit(lambda: lp.all_reduce(alg, scale=1.0 / world), iters=5, warmup=2)
+            per_rank = {"direct": n * esz * (1 + 1.0 / world) + n * esz * 2 * (world - 1) / world,
+                        "oneshot": n * esz * (world + 3), "ring": n * esz * (3 * (world - 1) / world + 2 * (world - 1) / world)}[alg]
+            res[f"p2p_{alg}_w{world}_n{n}_{str(dt)[6:]}"] = {"ms_all_virtual_ranks": t * 1e3,
+                                                             "ms_per_rank": t * 1e3 / world,
+                                                             "TBps_local": per_rank * world / t / 1e12}
+        del bufs, lp
+
     for k, v in res.items():
         print(k, json.dumps(v))
     if a.out:

@@ -1,0 +1,90 @@
+"""Runs each hot kernel a few times so that `rocprofv3 --pmc ...` can attach hardware counters to it.
+
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES ... --output-format csv -d gpurun_out/pmc_sq -- \
+        python3 tools/pmc_kernels.py
+
+The shapes are those of the ResNet-50 (batch 256) and BERT-base (batch 64 x 512) steps.
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_tensorflow_amd.ops import bucket as B  # noqa: E402
+from distributed_tensorflow_amd.ops import conv as C  # noqa: E402
+from distributed_tensorflow_amd.ops import gemm  # noqa: E402
+from distributed_tensorflow_amd.ops import layernorm as LN  # noqa: E402
+from distributed_tensorflow_amd.ops import norm as N  # noqa: E402
+from distributed_tensorflow_amd.ops import optim as K  # noqa: E402
+from distributed_tensorflow_amd.ops.softmax_ce import softmax_cross_entropy  # noqa: E402
+
+DEV = torch.device("cuda:0")
+ITERS = int(os.environ.get("PMC_ITERS", "3"))
+
+
+def rep(fn):
+    for _ in range(ITERS):
+        fn()
+    torch.cuda.synchronize()
+
+
+def main():
+    bf = torch.bfloat16
+    # GEMM: square, BERT FFN, ResNet 1x1 (as GEMM), wgrad shape
+    for (M, Nn, Kd) in [(4096, 4096, 4096), (32768, 3072, 768), (802816, 256, 64), (50176, 1024, 256)]:
+        A = torch.randn(M, Kd, device=DEV).to(bf)
+        W = torch.randn(Nn, Kd, device=DEV).to(bf)
+        G = torch.randn(M, Nn, device=DEV).to(bf)
+        rep(lambda: gemm.gemm_nt(A, W))
+        rep(lambda: gemm.gemm_nn(G, W))
+        rep(lambda: gemm.gemm_tn(G, A))
+        del A, W, G
+    # implicit-GEMM 3x3 convolution, fwd + bwd
+    C.set_convkxk_backend("gemm")
+    x = torch.randn(256, 128, 28, 28, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(128, 128, 3, 3, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
+    rep(lambda: C.conv2d(x, w, stride=1, padding=1).sum().backward())
+    C.set_convkxk_backend("library")
+    # batch norm + ReLU fwd/bwd on the largest ResNet-50 activation
+    xb = torch.randn(256, 256, 56, 56, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
+    g = torch.ones(256, device=DEV, requires_grad=True)
+    b = torch.zeros(256, device=DEV, requires_grad=True)
+    rm, rv = torch.zeros(256, device=DEV), torch.ones(256, device=DEV)
+    rep(lambda: N.batch_norm_act(xb, g, b, rm, rv, True, 0.1, 1e-5, relu=True).sum().backward())
+    del xb
+    # layer norm
+    xl = torch.randn(32768, 768, device=DEV).to(bf).requires_grad_(True)
+    gl = torch.ones(768, device=DEV, requires_grad=True)
+    bl = torch.zeros(768, device=DEV, requires_grad=True)
+    rep(lambda: LN.layer_norm(xl, gl, bl, 1e-12).sum().backward())
+    # softmax cross-entropy (ResNet head, BERT MLM head)
+    for (Bn, Cn) in [(256, 1000), (8192, 30522)]:
+        xs = torch.randn(Bn, Cn, device=DEV).to(bf).requires_grad_(True)
+        ys = torch.randint(0, Cn, (Bn,), device=DEV)
+        rep(lambda: softmax_cross_entropy(xs, ys, "mean").backward())
+        del xs
+    # optimizer + bucket kernels on a ResNet-50-sized arena
+    n = 25_600_000
+    p = torch.randn(n, device=DEV); gr = torch.randn(n, device=DEV).to(bf)
+    m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    sh = torch.zeros(n, device=DEV, dtype=bf)
+    h = K.OptHyper(DEV)
+    rep(lambda: K.adam_apply(p, gr, m, v, h, shadow=sh))
+    rep(lambda: K.sgdm_apply(p, gr, m, h, shadow=sh))
+    ts = [torch.randn(s, device=DEV, dtype=bf) for s in [2048 * 512, 512 * 512 * 9, 512 * 2048] * 6]
+    offs, o = [], 0
+    for t_ in ts:
+        offs.append(o); o += (t_.numel() + 63) // 64 * 64
+    flat = torch.empty(o, device=DEV, dtype=bf)
+    rep(lambda: B.flatten(ts, flat, offs, scale=0.125))
+    # peer-pointer reduce (8 local "peers")
+    from distributed_tensorflow_amd.comm.ipc import LocalPeers
+    bufs = [torch.randn(n, device=DEV).to(bf) for _ in range(8)]
+    lp = LocalPeers(bufs)
+    rep(lambda: lp.all_reduce("direct", scale=0.125))
+    print("pmc workload done")
+
+
+if __name__ == "__main__":
+    main()
