@@ -37,6 +37,7 @@ def main() -> int:
     ap.add_argument("--convkxk", default=None, choices=[None, "gemm", "library"])
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"], help="cpu is for plumbing tests only")
     ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -70,13 +71,18 @@ def main() -> int:
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
 
+    st.cfg.graph = bool(a.graph and dev.type == "cuda")
+    step = st.step_callable()
+    if st.cfg.graph:        # eager priming + capture happen before the counted warm-up steps
+        for _ in range(5):
+            step(x, y)
     for _ in range(a.warmup):
-        st.train_step(x, y)
+        step(x, y)
     sync()
     t0 = time.perf_counter()
     loss = None
     for _ in range(a.steps):
-        loss = st.train_step(x, y)
+        loss = step(x, y)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -94,7 +100,8 @@ def main() -> int:
             "config": {"model": "resnet50", "global_batch": a.batch * world, "per_gpu_batch": a.batch,
                        "image": a.image, "seq_len": None, "parallelism": f"dp{world}",
                        "strategy": "decentralized keras-style mirrored all-reduce (bucketed, overlapped)",
-                       "optimizer": "sgd-momentum (fused flat-arena kernel)", "conv1x1": conv.get_conv1x1_backend(), "convkxk": conv.get_convkxk_backend()},
+                       "optimizer": "sgd-momentum (fused flat-arena kernel)", "conv1x1": conv.get_conv1x1_backend(), "convkxk": conv.get_convkxk_backend(),
+                       "hip_graph": st.cfg.graph},
             "final_loss": loss_v,
         }), flush=True)
     comm.shutdown()

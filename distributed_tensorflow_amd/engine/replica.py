@@ -39,6 +39,7 @@ class TrainConfig:
     first_bucket_bytes: int | None = 8 << 20
     shard_ways: int = 1
     seed: int = 0
+    graph: bool = False                   # capture the whole train step into a hipGraph (GPU, static shapes)
     extra: dict = field(default_factory=dict)
 
 

@@ -26,6 +26,7 @@ from ..obs.metrics import MetricsLogger
 
 class Strategy:
     name = "base"
+    graph_capturable = False    # train_step is stream-ordered end to end (no host round trip inside)
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None,
                  metrics: MetricsLogger | None = None):
@@ -58,6 +59,18 @@ class Strategy:
     def train_step(self, x, y) -> torch.Tensor:  # pragma: no cover - interface
         raise NotImplementedError
 
+    def step_callable(self):
+        """``train_step``, or its hipGraph-captured form when ``cfg.graph`` asks for it."""
+        if self.cfg.graph and self.comm.device.type == "cuda":
+            if not self.graph_capturable:
+                raise ValueError(f"strategy {self.name!r} has host-side hand-offs inside a step and cannot be "
+                                 "captured into a graph")
+            if getattr(self, "_graphed", None) is None:
+                from ..engine.graph import GraphedStep
+                self._graphed = GraphedStep(self.train_step, self.comm.device)
+            return self._graphed
+        return self.train_step
+
     def apply_sparse(self) -> None:
         """Parameter-server apply of the sparse (embedding) gradients pushed during backward."""
         if self.sparse_modules:
@@ -87,6 +100,7 @@ class Strategy:
             steps_per_epoch = min(steps_per_epoch, max_steps)
         it_count = 0
         last_loss = None
+        step = self.step_callable()
         self.sync_device()
         self.comm.barrier()
         t0 = time.time()
@@ -98,7 +112,7 @@ class Strategy:
                 if fault_hook is not None:
                     fault_hook(self.comm.rank, it_count)
                 ts = time.time()
-                last_loss = self.train_step(x, y)
+                last_loss = step(x, y)
                 if verbose and it_count % 50 == 0 and self.comm.rank == 0:
                     print(it_count, flush=True)
                 if self.metrics.enabled:

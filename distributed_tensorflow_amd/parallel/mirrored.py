@@ -34,6 +34,7 @@ from .base import Strategy
 
 class MirroredStrategy(Strategy):
     name = "keras"
+    graph_capturable = True
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None, metrics=None):
         super().__init__(model, comm, cfg, optimizer, metrics)

@@ -41,6 +41,7 @@ from .base import Strategy
 
 
 class SyncPSStrategy(Strategy):
+    graph_capturable = True
     name = "sync"
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None, metrics=None,
