@@ -19,16 +19,19 @@ from distributed_tensorflow_amd.parallel.mirrored import MirroredStrategy  # noq
 DEV = torch.device("cuda:0")
 
 
-def run(name, st, x, y, steps, warmup, unit_count, unit):
-    for _ in range(warmup):
-        st.train_step(x, y)
+def run(name, st, x, y, steps, warmup, unit_count, unit, graph=False):
+    st.cfg.graph = graph
+    step = st.step_callable()
+    for _ in range(warmup + (5 if graph else 0)):
+        step(x, y)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = st.train_step(x, y)
+        loss = step(x, y)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    res = {"model": name, "ms_per_step": round(dt * 1e3, 3), unit: round(unit_count / dt, 1), "loss": float(loss)}
+    res = {"model": name, "hip_graph": graph, "ms_per_step": round(dt * 1e3, 3), unit: round(unit_count / dt, 1),
+           "loss": float(loss)}
     print(json.dumps(res), flush=True)
     return res
 
@@ -55,20 +58,32 @@ def main():
         torch.manual_seed(0)
         cfg = TrainConfig(param_dtype=torch.bfloat16, grad_dtype=torch.bfloat16)
         st = MirroredStrategy(resnet20(), comm, cfg, optimizer=SGD(0.1, momentum=0.9, formula="torch"))
-        x = torch.randn(1024, 32, 32, 3, device=DEV).to(torch.bfloat16)
-        y = torch.randint(0, 10, (1024,), device=DEV)
-        out.append(run("resnet20-cifar10-b1024", st, x, y, a.steps, a.warmup, 1024, "images_per_s"))
+        for bs in (1024, 128):
+            x = torch.randn(bs, 32, 32, 3, device=DEV).to(torch.bfloat16)
+            y = torch.randint(0, 10, (bs,), device=DEV)
+            for graph in (False, True):
+                out.append(run(f"resnet20-cifar10-b{bs}", st, x, y, a.steps * 3, a.warmup, bs, "images_per_s", graph))
+                st._graphed = None
         del st
     if "mlp" in a.models:
         from distributed_tensorflow_amd.models.mlp import reference_mlp
         torch.manual_seed(0)
         for dt, bs in ((None, 100), (torch.bfloat16, 100), (torch.bfloat16, 8192)):
             cfg = TrainConfig(param_dtype=dt)
-            st = MirroredStrategy(reference_mlp(), comm, cfg, optimizer=Adam())
             x = torch.rand(bs, 28, 28, 1, device=DEV)
             y = torch.randint(0, 10, (bs,), device=DEV, dtype=torch.int32)
-            out.append(run(f"reference-mlp-b{bs}-{'bf16' if dt else 'fp32'}", st, x, y, a.steps * 5, a.warmup, bs,
-                           "images_per_s"))
+            for graph in (False, True):
+                st = MirroredStrategy(reference_mlp(), comm, cfg, optimizer=Adam())
+                out.append(run(f"reference-mlp-b{bs}-{'bf16' if dt else 'fp32'}", st, x, y, a.steps * 20, a.warmup, bs,
+                               "images_per_s", graph))
+        # parameter-server step latency (push = reduce-scatter, fused apply on the shard, pull = all-gather)
+        from distributed_tensorflow_amd.parallel.ps import SyncPSStrategy
+        x = torch.rand(64, 28, 28, 1, device=DEV)
+        y = torch.randint(0, 10, (64,), device=DEV, dtype=torch.int32)
+        for graph in (False, True):
+            st = SyncPSStrategy(reference_mlp(), comm, TrainConfig(loss_reduction="sum"), optimizer=Adam())
+            out.append(run("ps-sync-step-latency-mlp-b64-fp32", st, x, y, a.steps * 20, a.warmup, 64, "images_per_s",
+                           graph))
     if "widedeep" in a.models:
         from distributed_tensorflow_amd.models.wide_deep import bench_step
         out.append(bench_step(DEV, a.steps, a.warmup))
