@@ -122,9 +122,13 @@ class Dense(Layer):
     def is_softmax(self) -> bool:
         return self.act == "softmax"
 
-    def forward(self, x, logits: bool = False):
+    def forward(self, x, logits: bool = False, dropout: float = 0.0):
+        """``dropout`` > 0 (set by ``Sequential`` when a ``Dropout`` layer follows) fuses the dropout
+        into this layer's GEMM epilogue."""
         fused = self.act_name if self.act_name in ("relu", "gelu") else None
-        y = _dense.linear(x, self.weight, self.bias, activation=fused)
+        if dropout and not (fused or self.act is None):
+            raise ValueError("dropout can only be fused behind a linear, relu or gelu Dense layer")
+        y = _dense.linear(x, self.weight, self.bias, activation=fused, dropout_p=dropout, training=self.training)
         if fused or self.act is None:
             return y
         if self.act == "softmax":

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import keras_weights as kw
-from .layers import Dense, Layer, _to_device_layout
+from .layers import Dense, Dropout, Layer, _to_device_layout
 
 
 class Model(nn.Module):
@@ -107,9 +107,17 @@ class Sequential(Model):
     def forward(self, x, logits: bool = False):
         x = self.prepare_input(x)
         n = len(self.layers)
+        skip = False
         for i, l in enumerate(self.layers):
+            if skip:            # a Dropout already applied inside the preceding Dense
+                skip = False
+                continue
             if i == n - 1 and logits and self.supports_logits:
                 x = l(x, logits=True)
+            elif (isinstance(l, Dense) and i + 1 < n and isinstance(self.layers[i + 1], Dropout)
+                  and (l.act is None or l.act_name in ("relu", "gelu"))):
+                x = l(x, dropout=self.layers[i + 1].rate)
+                skip = True
             else:
                 x = l(x)
         return x

@@ -75,6 +75,29 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
   return r;
 }
 
+// Philox4x32-10 counter-based generator: 4 x 32 random bits for (seed, counter). Dropout draws one
+// block per 4 consecutive elements of the output: counter = offset + (linear element index >> 2),
+// so the backward pass regenerates the forward mask from (seed, offset) instead of storing it.
+__device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned long long ctr, unsigned (&out)[4]) {
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// An element is dropped when its 32 random bits are below p * 2^32.
+inline unsigned dropout_threshold(float p) {
+  if (p <= 0.f) return 0u;
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+}
+
 inline int grid_for(long long n_items, int per_block) {
   long long b = (n_items + per_block - 1) / per_block;
   if (b < 1) b = 1;

@@ -24,36 +24,77 @@ __device__ __forceinline__ float gelu_df(float x) {
   return cdf + x * pdf;
 }
 
+// Dropout whose mask is regenerated from the forward pass's (seed, offset): see philox4x32_10.
+struct DropArgs {
+  unsigned thresh;       // 0 = no dropout
+  float scale;           // multiplies every kept element (1/(1-p), or any plain scale when thresh == 0)
+  unsigned long long seed;
+  const unsigned long long* off;
+};
+
 // op 0: dx = g * (y > 0)         (ReLU backward from the OUTPUT y)
 // op 1: dx = g * gelu'(x)        (GELU backward from the PRE-activation x)
 // op 2: y  = gelu(x)             (a = x, b unused)
-template <int OP>
+// op 3: out = a                  (b unused; with DropArgs: dropout forward or backward on its own)
+// With DROP the dropout mask and scale are applied to `a` FIRST (the gradient that arrives from
+// above passes the dropout layer before it reaches the activation), then the op.
+template <int OP, bool DROP>
 __global__ __launch_bounds__(kBlock) void ew_kernel(const unsigned short* __restrict__ a,
                                                     const unsigned short* __restrict__ b,
-                                                    unsigned short* __restrict__ out, long long n) {
+                                                    unsigned short* __restrict__ out, long long n, DropArgs d) {
   const long long n8 = n >> 3;
   const long long stride = (long long)gridDim.x * blockDim.x;
+  const unsigned long long off = DROP && d.thresh ? *d.off : 0ull;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
     float x[8], y[8];
     ld8(a + i * 8, x);
-    if (OP != 2) ld8(b + i * 8, y);
+    if (OP == 0 || OP == 1) ld8(b + i * 8, y);
+    if (DROP) {
+      if (d.thresh) {
+        unsigned r0[4], r1[4];
+        philox4x32_10(d.seed, off + (unsigned long long)(2 * i), r0);
+        philox4x32_10(d.seed, off + (unsigned long long)(2 * i + 1), r1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          x[k] = r0[k] >= d.thresh ? x[k] * d.scale : 0.f;
+          x[k + 4] = r1[k] >= d.thresh ? x[k + 4] * d.scale : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] *= d.scale;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (OP == 0) x[k] = y[k] > 0.f ? x[k] : 0.f;
       else if (OP == 1) x[k] = x[k] * gelu_df(y[k]);
-      else x[k] = gelu_f(x[k]);
+      else if (OP == 2) x[k] = gelu_f(x[k]);
     }
     st8(out + i * 8, x);
   }
   if (blockIdx.x == 0)
     for (long long i = (n8 << 3) + threadIdx.x; i < n; i += blockDim.x) {
       float x = bf16_to_f32(a[i]);
-      const float y = OP != 2 ? bf16_to_f32(b[i]) : 0.f;
+      const float y = (OP == 0 || OP == 1) ? bf16_to_f32(b[i]) : 0.f;
+      if (DROP) {
+        if (d.thresh) {
+          unsigned r[4];
+          philox4x32_10(d.seed, off + (unsigned long long)(i >> 2), r);
+          x = r[i & 3] >= d.thresh ? x * d.scale : 0.f;
+        } else {
+          x *= d.scale;
+        }
+      }
       if (OP == 0) x = y > 0.f ? x : 0.f;
       else if (OP == 1) x = x * gelu_df(y);
-      else x = gelu_f(x);
+      else if (OP == 2) x = gelu_f(x);
       out[i] = f32_to_bf16(x);
     }
+}
+
+// *counter += inc, on the device, so that a captured graph draws a fresh mask on every replay.
+__global__ void rng_tick_kernel(unsigned long long* counter, unsigned long long inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *counter += inc;
 }
 
 // out[n] += sum_m g[m][n] for a row-major bf16 [M][N] matrix (N % 8 == 0); out is fp32 and
@@ -93,12 +134,39 @@ DTF_API int dtf_ew_bf16(int op, const void* a, const void* b, void* out, long lo
   const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Bp = (const unsigned short*)b;
   unsigned short* O = (unsigned short*)out;
+  const DropArgs d = {0u, 1.f, 0ull, nullptr};
   switch (op) {
-    case 0: hipLaunchKernelGGL(ew_kernel<0>, dim3(grid), dim3(kBlock), 0, stream, A, Bp, O, n); break;
-    case 1: hipLaunchKernelGGL(ew_kernel<1>, dim3(grid), dim3(kBlock), 0, stream, A, Bp, O, n); break;
-    case 2: hipLaunchKernelGGL(ew_kernel<2>, dim3(grid), dim3(kBlock), 0, stream, A, Bp, O, n); break;
+    case 0: hipLaunchKernelGGL((ew_kernel<0, false>), dim3(grid), dim3(kBlock), 0, stream, A, Bp, O, n, d); break;
+    case 1: hipLaunchKernelGGL((ew_kernel<1, false>), dim3(grid), dim3(kBlock), 0, stream, A, Bp, O, n, d); break;
+    case 2: hipLaunchKernelGGL((ew_kernel<2, false>), dim3(grid), dim3(kBlock), 0, stream, A, Bp, O, n, d); break;
     default: return -1;
   }
+  return (int)hipGetLastError();
+}
+
+// The same ops with dropout (probability p, mask from philox(seed, *off + idx/4)) applied to `a`
+// first; op 3 is dropout alone. p == 0 with scale != 1 is a plain scaling.
+DTF_API int dtf_ew_drop_bf16(int op, const void* a, const void* b, void* out, long long n, float p, float scale,
+                             unsigned long long seed, const void* off, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (p < 0.f || p >= 1.f || (p > 0.f && !off)) return -1;
+  const int grid = grid_for((n + 7) / 8, kBlock);
+  const unsigned short* A = (const unsigned short*)a;
+  const unsigned short* Bp = (const unsigned short*)b;
+  unsigned short* O = (unsigned short*)out;
+  const DropArgs d = {dropout_threshold(p), p > 0.f ? 1.f / (1.f - p) : scale, seed, (const unsigned long long*)off};
+  switch (op) {
+    case 0: hipLaunchKernelGGL((ew_kernel<0, true>), dim3(grid), dim3(kBlock), 0, stream, A, Bp, O, n, d); break;
+    case 1: hipLaunchKernelGGL((ew_kernel<1, true>), dim3(grid), dim3(kBlock), 0, stream, A, Bp, O, n, d); break;
+    case 3: hipLaunchKernelGGL((ew_kernel<3, true>), dim3(grid), dim3(kBlock), 0, stream, A, Bp, O, n, d); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+DTF_API int dtf_rng_tick(void* counter, unsigned long long inc, hipStream_t stream) {
+  if (!counter) return -1;
+  hipLaunchKernelGGL(rng_tick_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long*)counter, inc);
   return (int)hipGetLastError();
 }
 

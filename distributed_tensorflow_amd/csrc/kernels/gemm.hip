@@ -84,6 +84,11 @@ struct GemmArgs {
   // batched GEMM: blockIdx.z = b1 * nb2 + b2; operand offsets b1 * s?1 + b2 * s?2 (elements)
   int nb2;
   long long sA1, sA2, sB1, sB2, sC1, sC2;
+  // dropout in the epilogue (after the activation): drop where philox(seed, *off + idx/4) < thresh
+  unsigned drop_thresh;  // 0 = no dropout
+  float drop_scale;      // 1 / (1 - p)
+  unsigned long long drop_seed;
+  const unsigned long long* drop_off;
   ConvGeom cv;
 };
 
@@ -438,6 +443,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
         acc[i][j][r] = v;
       }
   }
+  if (g.drop_thresh) {
+    const unsigned long long off = *g.drop_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long m = wm0 + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = wn0 + j * 16 + fq * 4;
+        unsigned rnd[4];
+        philox4x32_10(g.drop_seed, off + (unsigned long long)((m * g.N + n) >> 2), rnd);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = rnd[r] >= g.drop_thresh ? acc[i][j][r] * g.drop_scale : 0.f;
+      }
+    }
+  }
 
   if (g.out_fp32) {
     float* C = reinterpret_cast<float*>(g.C) + c_off;
@@ -568,6 +588,10 @@ struct GemmExtra {
   int conv;                          // 0 plain, 1 conv forward, 2 conv dgrad, 3 conv wgrad
   int H, W, OH, OW, S, P, KH, KW, CI, CO, NB;
   const void* Cin;                   // optional bf16 tensor added to the output
+  float drop_p;                      // dropout probability applied after the activation (0 = none)
+  int drop_pad;
+  unsigned long long drop_seed;
+  const void* drop_off;              // device pointer to the 64-bit Philox offset of this call
 };
 
 static int gemm_launch(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
@@ -580,6 +604,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   g.bias = bias; g.Cin = nullptr; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.bias_dtype = bias_dtype; g.act = act; g.out_fp32 = out_fp32;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0; g.drop_off = nullptr;
   int batch = 1, conv = 0;
   g.nb2 = 1; g.sA1 = g.sA2 = g.sB1 = g.sB2 = g.sC1 = g.sC2 = 0;
   ConvGeom& c = g.cv;
@@ -590,6 +615,14 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
     batch = nb1 * g.nb2;
     g.sA1 = ex->sA1; g.sA2 = ex->sA2; g.sB1 = ex->sB1; g.sB2 = ex->sB2; g.sC1 = ex->sC1; g.sC2 = ex->sC2;
     g.Cin = (const unsigned short*)ex->Cin;
+    if (ex->drop_p > 0.f) {
+      if (!ex->drop_off || ex->drop_p >= 1.f || ex->conv || ex->nb1 > 1 || ex->nb2 > 1) return -8;
+      g.drop_thresh = dropout_threshold(ex->drop_p);
+      g.drop_scale = 1.f / (1.f - ex->drop_p);
+      g.drop_seed = ex->drop_seed;
+      g.drop_off = (const unsigned long long*)ex->drop_off;
+      splits = 1;                                      // the mask is applied in this kernel's epilogue
+    }
     conv = ex->conv;
     if (conv) {
       c.H = ex->H; c.W = ex->W; c.OH = ex->OH; c.OW = ex->OW; c.S = ex->S; c.P = ex->P; c.KH = ex->KH; c.KW = ex->KW;

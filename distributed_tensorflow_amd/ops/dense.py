@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from . import gemm as _gemm
+from . import rng as _rng
 
 
 def _act_fwd(y, activation):
@@ -27,16 +28,26 @@ class _LinearFn(torch.autograd.Function):
     """bf16 GPU path: every GEMM on the MFMA kernel, epilogues fused."""
 
     @staticmethod
-    def forward(ctx, x, w, b, activation):
+    def forward(ctx, x, w, b, activation, drop_p=0.0):
         x2 = x.reshape(-1, x.shape[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
+        ctx.drop = None
+        drop = None
+        if drop_p > 0.0:
+            st = _rng.state_for(x.device)
+            ctx.drop = (drop_p, st.seed, st.snapshot())
+            drop = ctx.drop
         if activation == "gelu":
             saved = _gemm.gemm_nt(x2, w, bias=b, activation=None)          # pre-activation
             y = _gemm.gelu_fwd(saved)
+            if drop is not None:
+                y = _gemm.dropout_fwd(y, *drop)
         else:
-            y = _gemm.gemm_nt(x2, w, bias=b, activation=activation)        # [M, N]
+            y = _gemm.gemm_nt(x2, w, bias=b, activation=activation, dropout=drop)   # [M, N]
             saved = y if activation == "relu" else None
+        if drop is not None:
+            st.advance(y.numel())
         ctx.activation = activation
         ctx.bias_dtype = b.dtype if b is not None else None
         ctx.x_shape = x.shape
@@ -47,7 +58,9 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, gy):
         x2, w, saved = ctx.saved_tensors
         g = gy.reshape(-1, gy.shape[-1])
-        if ctx.activation == "relu":
+        if ctx.drop is not None:
+            g = _gemm.dropout_bwd(g, *ctx.drop, activation=ctx.activation, saved=saved)
+        elif ctx.activation == "relu":
             g = _gemm.relu_bwd(g, saved)
         elif ctx.activation == "gelu":
             g = _gemm.gelu_bwd(g, saved)
@@ -59,15 +72,19 @@ class _LinearFn(torch.autograd.Function):
             gb = _gemm.col_sum(g, dtype=ctx.bias_dtype)
         if gx is not None:
             gx = gx.reshape(ctx.x_shape)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
-           activation: str | None = None) -> torch.Tensor:
-    """``act(x @ weight.T + bias)`` with ``weight`` in torch ``(out, in)`` layout."""
+           activation: str | None = None, dropout_p: float = 0.0, training: bool = False) -> torch.Tensor:
+    """``dropout(act(x @ weight.T + bias))`` with ``weight`` in torch ``(out, in)`` layout. On the bf16
+    GPU path the dropout mask comes from the Philox state of ``ops/rng.py`` and is applied in the
+    GEMM epilogue; elsewhere ``torch.nn.functional.dropout`` is used."""
+    p = float(dropout_p) if training else 0.0
     if x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and _gemm.supported(x, weight):
-        return _LinearFn.apply(x, weight, bias, activation)
+        return _LinearFn.apply(x, weight, bias, activation, p)
     if x.dtype != weight.dtype:
         x = x.to(weight.dtype)
     y = F.linear(x, weight, bias.to(weight.dtype) if bias is not None else None)
-    return _act_fwd(y, activation)
+    y = _act_fwd(y, activation)
+    return F.dropout(y, p, True) if p > 0.0 else y

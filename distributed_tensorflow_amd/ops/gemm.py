@@ -45,7 +45,9 @@ class GemmExtra(ctypes.Structure):
                 ("conv", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("OH", ctypes.c_int),
                 ("OW", ctypes.c_int), ("S", ctypes.c_int), ("P", ctypes.c_int), ("KH", ctypes.c_int),
                 ("KW", ctypes.c_int), ("CI", ctypes.c_int), ("CO", ctypes.c_int), ("NB", ctypes.c_int),
-                ("Cin", ctypes.c_void_p)]
+                ("Cin", ctypes.c_void_p),
+                ("drop_p", ctypes.c_float), ("drop_pad", ctypes.c_int), ("drop_seed", ctypes.c_ulonglong),
+                ("drop_off", ctypes.c_void_p)]
 
 
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 1, 2, 3
@@ -130,12 +132,21 @@ def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, s
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, activation=None, out_dtype=torch.bfloat16, splits=None,
-            out=None) -> torch.Tensor:
-    """``act(a[M,K] @ b[N,K]^T + bias)``."""
+            out=None, dropout=None) -> torch.Tensor:
+    """``dropout(act(a[M,K] @ b[N,K]^T + bias))``. ``dropout = (p, seed, offset_tensor)`` applies Philox
+    dropout in the epilogue (``offset_tensor``: int64 device scalar, see ``ops/rng.py``)."""
     if not (_ok2d(a) and _ok2d(b)) or a.shape[1] != b.shape[1]:
         raise ValueError("gemm_nt: operands must be 16-byte aligned bf16 [M,K] and [N,K]")
+    extra = None
+    if dropout is not None and dropout[0] > 0.0:
+        if out_dtype != torch.bfloat16 or (out is not None and out.stride(0) != b.shape[0]):
+            raise ValueError("gemm_nt: fused dropout needs a dense bf16 output")
+        extra = GemmExtra()
+        extra.nb1 = extra.nb2 = 1
+        extra.drop_p, extra.drop_seed, extra.drop_off = float(dropout[0]), int(dropout[1]), dropout[2].data_ptr()
+        splits = 1
     return _launch(NT, a, b, a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0), bias, activation,
-                   out_dtype, splits, out)
+                   out_dtype, splits, out, extra=extra)
 
 
 def gemm_nn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=None, out=None) -> torch.Tensor:
@@ -184,6 +195,35 @@ def _ew(op: int, a: torch.Tensor, b: torch.Tensor | None) -> torch.Tensor:
                                     _lib.stream_ptr(a.device))
     _lib.check(rc, "ew_bf16")
     return out
+
+
+def _ew_drop(op: int, a: torch.Tensor, b: torch.Tensor | None, p: float, scale: float, seed: int,
+             off: torch.Tensor | None) -> torch.Tensor:
+    a = a.contiguous()
+    if b is not None:
+        b = b.contiguous()
+    out = torch.empty_like(a)
+    rc = _lib.kernels().dtf_ew_drop_bf16(op, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), ctypes.c_longlong(a.numel()),
+                                         ctypes.c_float(p), ctypes.c_float(scale), ctypes.c_ulonglong(seed),
+                                         _lib.ptr(off), _lib.stream_ptr(a.device))
+    _lib.check(rc, "ew_drop_bf16")
+    return out
+
+
+def dropout_fwd(x: torch.Tensor, p: float, seed: int, off: torch.Tensor) -> torch.Tensor:
+    """Philox dropout of a contiguous bf16 tensor (mask = f(seed, off, linear index))."""
+    return _ew_drop(3, x, None, p, 1.0, seed, off)
+
+
+def dropout_bwd(g: torch.Tensor, p: float, seed: int, off: torch.Tensor, activation: str | None = None,
+                saved: torch.Tensor | None = None) -> torch.Tensor:
+    """Gradient through ``dropout(act(z))``: the forward mask is regenerated from ``(seed, off)``.
+    ``saved`` is the layer OUTPUT for relu and the PRE-activation for gelu."""
+    if activation == "relu":      # y > 0 already implies "kept": only the 1/(1-p) scale is needed
+        return _ew_drop(0, g, saved, 0.0, 1.0 / (1.0 - p), 0, None)
+    if activation == "gelu":
+        return _ew_drop(1, g, saved, p, 1.0, seed, off)
+    return _ew_drop(3, g, None, p, 1.0, seed, off)
 
 
 def relu_bwd(g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

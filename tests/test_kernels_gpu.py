@@ -417,3 +417,70 @@ def test_bert_tiny_trains_on_gpu():
     for _ in range(8):
         losses.append(float(rep.forward_backward(x, y))); rep.finish_backward(); opt.step()
     assert all(l == l for l in losses) and losses[-1] < losses[0] - 0.3
+
+
+# ------------------------------------------------------------------ fused Philox dropout
+@pytest.mark.gpu
+@pytest.mark.parametrize("activation", [None, "relu", "gelu"])
+def test_dense_fused_dropout_matches_philox_reference(activation):
+    """The GEMM-epilogue dropout mask equals the NumPy Philox reference, forward and backward."""
+    import numpy as np
+    from distributed_tensorflow_amd.ops import dense, rng
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1234)
+    M, K, N, p = 200, 64, 136, 0.3
+    x = torch.randn(M, K, device=dev).bfloat16().requires_grad_(True)
+    w = (torch.randn(N, K, device=dev) * 0.2).bfloat16().requires_grad_(True)
+    b = torch.randn(N, device=dev).bfloat16().requires_grad_(True)
+    st = rng.state_for(dev)
+    off0 = int(st.offset.item())
+    y = dense.linear(x, w, b, activation=activation, dropout_p=p, training=True)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    assert int(st.offset.item()) == off0 + (M * N + 3) // 4          # the device counter advanced
+    keep = torch.from_numpy(rng.dropout_keep_mask_reference(st.seed, off0, M * N, p)).view(M, N).to(dev)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+    # reference with the same mask in fp32
+    xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+    z = xr @ wr.t() + br
+    a = torch.relu(z) if activation == "relu" else (torch.nn.functional.gelu(z) if activation == "gelu" else z)
+    yr = a * keep / (1 - p)
+    yr.backward(gy.float())
+    assert torch.equal((y != 0), (yr.bfloat16() != 0)) or float(((y != 0) != (yr != 0)).float().mean()) < 2e-3
+    assert torch.allclose(y.float(), yr, atol=0.06, rtol=0.03)
+    assert torch.allclose(x.grad.float(), xr.grad, atol=0.15, rtol=0.05)
+    assert torch.allclose(w.grad.float(), wr.grad, atol=0.5, rtol=0.05)
+    assert torch.allclose(b.grad.float(), br.grad, atol=0.3, rtol=0.05)
+    # eval mode: no dropout, counter untouched
+    y2 = dense.linear(x, w, b, activation=activation, dropout_p=p, training=False)
+    assert int(st.offset.item()) == off0 + (M * N + 3) // 4
+    assert float((y2 == 0).float().mean()) < (0.6 if activation == "relu" else 0.01)
+
+
+@pytest.mark.gpu
+def test_sequential_fuses_dropout_and_graph_replays_draw_fresh_masks():
+    from distributed_tensorflow_amd.api.layers import Dense, Dropout, Flatten
+    from distributed_tensorflow_amd.api.model import Sequential
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    m = Sequential([Flatten(input_shape=(16, 16)), Dense(256, activation="relu"), Dropout(0.5), Dense(16)]).to(dev)
+    for prm in m.parameters():
+        prm.data = prm.data.bfloat16()
+    x = torch.rand(64, 16, 16, device=dev).bfloat16()
+    m.train()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        m(x)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.no_grad(), torch.cuda.graph(g):
+        out = m(x)
+    g.replay(); a = out.clone()
+    g.replay(); b = out.clone()
+    assert not torch.equal(a, b)                 # the device-side offset advanced between replays
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x), m(x))
