@@ -77,6 +77,9 @@ class Model(nn.Module):
         p = next(self.parameters(), None)
         if p is not None and x.is_floating_point() and x.dtype != p.dtype:
             x = x.to(p.dtype)
+        shape = getattr(self, "input_shape_", None)
+        if shape is not None and len(shape) == 3 and shape[-1] == 1 and x.dim() == 3:
+            x = x.unsqueeze(-1)      # grey-scale images fed without their channel axis ([N, H, W])
         if x.dim() == 4 and self.input_layout == "NHWC":
             x = _to_device_layout(x)
         return x
