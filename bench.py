@@ -33,8 +33,8 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DTF_BENCH_BATCH", "256")), help="per-GPU batch")
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--bucket-mb", type=int, default=48)
-    ap.add_argument("--conv1x1", default=None, choices=[None, "gemm", "library"])
-    ap.add_argument("--convkxk", default=None, choices=[None, "gemm", "library"])
+    ap.add_argument("--conv1x1", default=None, choices=[None, "auto", "gemm", "library"])
+    ap.add_argument("--convkxk", default=None, choices=[None, "auto", "gemm", "library"])
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"], help="cpu is for plumbing tests only")
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph")

@@ -290,7 +290,7 @@ __device__ __forceinline__ bf16x8_t load_frag(const char* lds, int row0, int ks,
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <int A_T, int B_T, int CONV>
+template <int A_T, int B_T, int CONV, int STAGES>
 __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 tiles: A0 B0 A1 B1 (64 KiB)
 
@@ -304,7 +304,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   const int vt = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
   const int tile = vt / ntaps;
   const int tap = vt - tile * ntaps;
-  const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+  int tm = tile / g.tiles_n;
+  const int tn = tile % g.tiles_n;
+  // Strided data gradient: rows are ordered by parity class and the classes do unequal work (a class
+  // is reached by 0..4 of the filter taps), while an XCD owns a contiguous range of tiles. Deal the
+  // row tiles of the four classes out round-robin so that every XCD gets the same mix.
+  if (CONV == 2 && g.cv.S == 2 && (g.tiles_m & 3) == 0) tm = (tm & 3) * (g.tiles_m >> 2) + (tm >> 2);
   const int m0 = tm * BM, n0 = tn * BN;
   const int split = blockIdx.y;
   const int plane = CONV == 3 ? tap : (int)blockIdx.z;
@@ -357,25 +362,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     return t;
   };
 
-  int t = next_tile(0);
-  if (t < nt) {
-    sa.load(g, Ap, g.lda, g.M, m0, kbeg + t * BK, kend, tap);
-    sb.load(g, Bp, g.ldb, g.N, n0, kbeg + t * BK, kend, tap);
-    sa.store(smem);
-    sb.store(smem + kTileBytes);
-  }
-  __syncthreads();
-
-  int cur = 0;
-  while (t < nt) {
-    const int tnext = next_tile(t + 1);
-    const bool more = tnext < nt;
-    if (more) {
-      const int k0 = kbeg + tnext * BK;
-      sa.load(g, Ap, g.lda, g.M, m0, k0, kend, tap);
-      sb.load(g, Bp, g.ldb, g.N, n0, k0, kend, tap);
-    }
-    const char* la = smem + cur * 2 * kTileBytes;
+  auto compute = [&](const char* la) {
     const char* lb = la + kTileBytes;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -391,14 +378,59 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
           // swapped operands: result register r of lane l is C[m = i*16 + (l&15)][n = j*16 + (l>>4)*4 + r]
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
     }
-    if (more) {
-      char* na = smem + (cur ^ 1) * 2 * kTileBytes;
-      sa.store(na);
-      sb.store(na + kTileBytes);
+  };
+
+  int t = next_tile(0);
+  if (STAGES == 2) {
+    // two LDS buffers (64 KiB, 2 blocks per CU): the next tile is written while this one is read
+    if (t < nt) {
+      sa.load(g, Ap, g.lda, g.M, m0, kbeg + t * BK, kend, tap);
+      sb.load(g, Bp, g.ldb, g.N, n0, kbeg + t * BK, kend, tap);
+      sa.store(smem);
+      sb.store(smem + kTileBytes);
     }
     __syncthreads();
-    cur ^= 1;
-    t = tnext;
+    int cur = 0;
+    while (t < nt) {
+      const int tnext = next_tile(t + 1);
+      const bool more = tnext < nt;
+      if (more) {
+        const int k0 = kbeg + tnext * BK;
+        sa.load(g, Ap, g.lda, g.M, m0, k0, kend, tap);
+        sb.load(g, Bp, g.ldb, g.N, n0, k0, kend, tap);
+      }
+      compute(smem + cur * 2 * kTileBytes);
+      if (more) {
+        char* na = smem + (cur ^ 1) * 2 * kTileBytes;
+        sa.store(na);
+        sb.store(na + kTileBytes);
+      }
+      __syncthreads();
+      cur ^= 1;
+      t = tnext;
+    }
+  } else {
+    // one LDS buffer (32 KiB, up to 5 blocks per CU): the next tile waits in registers while this one
+    // is read. For short-K, bandwidth-bound shapes the extra resident blocks hide more latency than
+    // the second buffer does.
+    if (t < nt) {
+      sa.load(g, Ap, g.lda, g.M, m0, kbeg + t * BK, kend, tap);
+      sb.load(g, Bp, g.ldb, g.N, n0, kbeg + t * BK, kend, tap);
+    }
+    while (t < nt) {
+      sa.store(smem);
+      sb.store(smem + kTileBytes);
+      __syncthreads();
+      const int tnext = next_tile(t + 1);
+      if (tnext < nt) {
+        const int k0 = kbeg + tnext * BK;
+        sa.load(g, Ap, g.lda, g.M, m0, k0, kend, tap);
+        sb.load(g, Bp, g.ldb, g.N, n0, k0, kend, tap);
+      }
+      compute(smem);
+      __syncthreads();
+      t = tnext;
+    }
   }
 
   // ---- epilogue ---------------------------------------------------------------------
@@ -594,6 +626,12 @@ struct GemmExtra {
   const void* drop_off;              // device pointer to the 64-bit Philox offset of this call
 };
 
+static int g_stages = 0;                 // 0 = automatic
+constexpr int kSingleStageTiles = 32;
+
+// 0 = choose per launch, 1 = one LDS buffer, 2 = two LDS buffers (measurement hook).
+DTF_API void dtf_gemm_set_stages(int stages) { g_stages = stages; }
+
 static int gemm_launch(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                        long long lda, long long ldb, long long ldc, int bias_dtype, int act, int out_fp32,
                        int splits, void* workspace, const GemmExtra* ex, hipStream_t stream) {
@@ -645,8 +683,17 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   if (splits > 1 && !workspace) return -3;
   // the taps of a weight-gradient launch are folded into grid.x (see the kernel's tile map)
   const dim3 grid(g.tiles_m * g.tiles_n * (conv == 3 ? batch : 1), splits, conv == 3 ? 1 : batch);
-  const size_t lds = 4 * kTileBytes;
-#define GEMM_LAUNCH(AT, BT, CV) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV>), grid, dim3(kThreads), lds, stream, g)
+  // LDS stages: two buffers pay when a block runs a long k-loop at ~2 blocks per CU; short loops
+  // (k-tiles per block <= kSingleStageTiles) are latency- and bandwidth-bound and run better with one
+  // buffer and twice the resident blocks. g_stages overrides (1 or 2) for A/B measurements.
+  const int k_tiles = kps / BK;
+  const int stages = g_stages == 1 || g_stages == 2 ? g_stages : (k_tiles <= kSingleStageTiles ? 1 : 2);
+  const size_t lds = (stages == 2 ? 4 : 2) * kTileBytes;
+#define GEMM_LAUNCH(AT, BT, CV)                                                                              \
+  do {                                                                                                       \
+    if (stages == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 2>), grid, dim3(kThreads), lds, stream, g); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 1>), grid, dim3(kThreads), lds, stream, g);        \
+  } while (0)
   if (conv == 0) {
     switch (layout) {
       case 0: GEMM_LAUNCH(0, 0, 0); break;

@@ -8,8 +8,11 @@ Routing:
   larger kernels and strides gather the shifted / strided pixels while the operand is staged.
 * everything else (the stem, fp32, odd channel counts) goes to the vendor convolution library.
 
-``set_conv1x1_backend`` / ``set_convkxk_backend`` (``'gemm' | 'library'``, defaults from the
-``DTF_CONV1X1`` / ``DTF_CONVKXK`` environment variables) switch the routes, e.g. for A/B timing.
+``set_conv1x1_backend`` / ``set_convkxk_backend`` (``'auto' | 'gemm' | 'library'``, defaults from
+the ``DTF_CONV1X1`` / ``DTF_CONVKXK`` environment variables) switch the routes, e.g. for A/B timing.
+``'auto'`` decides per pass from measurements on MI355X (``tools/bench_conv.py``): the forward
+pass always runs on the own kernel; the data gradient of a strided convolution and the passes
+of 64-channel 3x3 layers, where the vendor library measured faster, go to the library.
 """
 from __future__ import annotations
 
@@ -20,14 +23,15 @@ import torch.nn.functional as F
 
 from . import gemm as _gemm
 
-_backend = os.environ.get("DTF_CONV1X1", "gemm")
-_backend_kxk = os.environ.get("DTF_CONVKXK", "library")
+_backend = os.environ.get("DTF_CONV1X1", "auto")
+_backend_kxk = os.environ.get("DTF_CONVKXK", "auto")
+_NAMES = ("auto", "gemm", "library")
 
 
 def set_conv1x1_backend(name: str) -> None:
     global _backend
-    if name not in ("gemm", "library"):
-        raise ValueError("backend must be 'gemm' or 'library'")
+    if name not in _NAMES:
+        raise ValueError("backend must be 'auto', 'gemm' or 'library'")
     _backend = name
 
 
@@ -39,8 +43,8 @@ def set_convkxk_backend(name: str) -> None:
     """Route of convolutions with a kernel larger than 1x1: 'gemm' (implicit GEMM on the MFMA kernel)
     or 'library' (vendor convolution library)."""
     global _backend_kxk
-    if name not in ("gemm", "library"):
-        raise ValueError("backend must be 'gemm' or 'library'")
+    if name not in _NAMES:
+        raise ValueError("backend must be 'auto', 'gemm' or 'library'")
     _backend_kxk = name
 
 
@@ -55,7 +59,7 @@ class _ConvFn(torch.autograd.Function):
     gradient is accumulated onto inside the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding):
+    def forward(ctx, x, w, stride, padding, auto=False):
         N, C, H, W = x.shape
         K, _, KH, KW = w.shape
         OH = (H + 2 * padding - KH) // stride + 1
@@ -69,6 +73,7 @@ class _ConvFn(torch.autograd.Function):
             _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, KH * KW * C, C, KH * KW * C, K, extra=ex)
         ctx.save_for_backward(x, w)
         ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, stride, padding)
+        ctx.auto = auto
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -79,7 +84,19 @@ class _ConvFn(torch.autograd.Function):
             gy = gy.contiguous(memory_format=torch.channels_last)
         plain = KH == 1 and KW == 1 and stride == 1 and padding == 0
         gx = gw = None
-        if ctx.needs_input_grad[0]:
+        # per-pass routing of 'auto' (see the module docstring)
+        lib_dgrad = ctx.auto and (stride != 1 or (KH * KW > 1 and K < 128))
+        lib_wgrad = ctx.auto and KH * KW > 1 and C < 128
+        want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if (want_x and lib_dgrad) or (want_w and lib_wgrad):
+            mask = [bool(want_x and lib_dgrad), bool(want_w and lib_wgrad), False]
+            lgx, lgw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [stride, stride], [padding, padding],
+                                                              [1, 1], False, [0, 0], 1, mask)
+            if mask[0]:
+                gx, want_x = lgx, False
+            if mask[1]:
+                gw, want_w = lgw, False
+        if want_x:
             gx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
             if plain:
                 _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, K, K, C, C)
@@ -87,7 +104,7 @@ class _ConvFn(torch.autograd.Function):
                 ex = _gemm.conv_geom(_gemm.CONV_DGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, KH * KW * K, K, KH * KW * C, C, extra=ex)
             gx = gx.permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
+        if want_w:
             gw = torch.empty((K, KH, KW, C), dtype=w.dtype, device=x.device)
             if plain:
                 _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, C)
@@ -95,7 +112,7 @@ class _ConvFn(torch.autograd.Function):
                 ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex)
             gw = gw.permute(0, 3, 1, 2)        # [K, C, KH, KW] with channels_last strides
-        return gx, gw, None, None
+        return gx, gw, None, None, None
 
 
 def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -109,9 +126,9 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0) 
     """Bias-free convolution of a channels_last activation with an ``[O, I, kh, kw]`` weight."""
     one = w.shape[2] == 1 and w.shape[3] == 1
     backend = _backend if one else _backend_kxk
-    if backend == "gemm" and stride in (1, 2) and _gemm_ok(x, w) and (stride == 1 or (x.shape[2] % 2 == 0 and
-                                                                                 x.shape[3] % 2 == 0)):
-        return _ConvFn.apply(x, w, stride, padding)
+    if backend != "library" and stride in (1, 2) and _gemm_ok(x, w) and (stride == 1 or (x.shape[2] % 2 == 0 and
+                                                                                    x.shape[3] % 2 == 0)):
+        return _ConvFn.apply(x, w, stride, padding, backend == "auto")
     if x.dtype != w.dtype:
         x = x.to(w.dtype)
     return F.conv2d(x, w, None, stride, padding)

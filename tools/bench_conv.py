@@ -1,0 +1,56 @@
+"""Times forward / data-gradient / weight-gradient of single convolutions, own kernel vs vendor library.
+
+usage: python tools/bench_conv.py            (ResNet-50 batch-256 strided and 3x3 shapes)
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_tensorflow_amd.ops import conv as C  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def timeit(fn, iters=10, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+def main():
+    shapes = [  # N, CI, H, W, CO, k, stride, pad
+        (256, 256, 56, 56, 512, 1, 2, 0), (256, 512, 28, 28, 1024, 1, 2, 0), (256, 1024, 14, 14, 2048, 1, 2, 0),
+        (256, 128, 56, 56, 128, 3, 2, 1), (256, 256, 28, 28, 256, 3, 2, 1), (256, 512, 14, 14, 512, 3, 2, 1),
+        (256, 64, 56, 56, 64, 3, 1, 1), (256, 128, 28, 28, 128, 3, 1, 1), (256, 256, 14, 14, 256, 3, 1, 1),
+        (256, 512, 7, 7, 512, 3, 1, 1),
+    ]
+    print(f"{'shape':44s} {'backend':8s} {'fwd_us':>8s} {'dgrad_us':>9s} {'wgrad_us':>9s}")
+    for (N, CI, H, W, CO, k, s, p) in shapes:
+        x = torch.randn(N, CI, H, W, device=DEV).bfloat16().to(memory_format=torch.channels_last).requires_grad_(True)
+        w = (torch.randn(CO, CI, k, k, device=DEV) * 0.05).bfloat16().to(memory_format=torch.channels_last).requires_grad_(True)
+        for backend in ("gemm", "library"):
+            C.set_conv1x1_backend(backend)
+            C.set_convkxk_backend(backend)
+            xd, wd = x.detach(), w.detach()
+            yd = C.conv2d(x, wd, stride=s, padding=p)      # only the data gradient is needed
+            yw = C.conv2d(xd, w, stride=s, padding=p)      # only the weight gradient is needed
+            gy = torch.randn_like(yd)
+            with torch.no_grad():
+                tf = timeit(lambda: C.conv2d(xd, wd, stride=s, padding=p))
+            td = timeit(lambda: torch.autograd.grad(yd, x, gy, retain_graph=True))
+            tw = timeit(lambda: torch.autograd.grad(yw, w, gy, retain_graph=True))
+            print(f"{str((N, CI, H, W, CO, k, s, p)):44s} {backend:8s} {tf:8.1f} {td:9.1f} {tw:9.1f}", flush=True)
+        del x, w, yd, yw, gy
+
+
+if __name__ == "__main__":
+    main()

@@ -45,7 +45,7 @@ def main():
     x = torch.randn(256, 128, 28, 28, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
     w = torch.randn(128, 128, 3, 3, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
     rep(lambda: C.conv2d(x, w, stride=1, padding=1).sum().backward())
-    C.set_convkxk_backend("library")
+    C.set_convkxk_backend("auto")
     # batch norm + ReLU fwd/bwd on the largest ResNet-50 activation
     xb = torch.randn(256, 256, 56, 56, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
     g = torch.ones(256, device=DEV, requires_grad=True)
