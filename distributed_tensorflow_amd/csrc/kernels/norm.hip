@@ -103,25 +103,29 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short
   }
 }
 
-// Sum of the per-block partials for 32 channels per 256-thread block: lane (c = tid & 31) x
-// partial-lane (tid >> 5) strides over the partials with 4 loads in flight, then the 8
-// partial-lanes are combined through LDS in a fixed order (bitwise reproducible).
+// Sum of the per-block partials for kFinCh channels per 256-thread block: lane (c = tid % kFinCh) x
+// partial-lane (tid / kFinCh) strides over the partials with 4 loads in flight, then the
+// partial-lanes are combined through LDS in a fixed order (bitwise reproducible). Few channels per
+// block means many blocks: the kernel is latency-bound, so it wants the whole chip.
+constexpr int kFinCh = 8;
+constexpr int kFinLanes = kBlock / kFinCh;   // 32
+
 __device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ part, int n_part, int C, float& s0, float& s1) {
-  __shared__ float red[2][8][32];
-  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float red[2][kFinLanes][kFinCh];
+  const int cl = threadIdx.x % kFinCh, pl = threadIdx.x / kFinCh;
+  const int c = blockIdx.x * kFinCh + cl;
   float a0 = 0.f, a1 = 0.f;
   if (c < C) {
     int p = pl;
-    for (; p + 24 < n_part; p += 32) {
+    for (; p + 3 * kFinLanes < n_part; p += 4 * kFinLanes) {
       const float* q = part + (long long)p * 2 * C + c;
-      const long long st = (long long)16 * C;   // 8 partials ahead
+      const long long st = (long long)2 * kFinLanes * C;   // kFinLanes partials ahead
       float x0 = q[0], y0 = q[C], x1 = q[st], y1 = q[st + C], x2 = q[2 * st], y2 = q[2 * st + C], x3 = q[3 * st],
             y3 = q[3 * st + C];
       a0 += (x0 + x1) + (x2 + x3);
       a1 += (y0 + y1) + (y2 + y3);
     }
-    for (; p < n_part; p += 8) {
+    for (; p < n_part; p += kFinLanes) {
       a0 += part[(long long)p * 2 * C + c];
       a1 += part[(long long)p * 2 * C + C + c];
     }
@@ -131,12 +135,12 @@ __device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ part, 
   if (pl != 0 || c >= C) return false;
   s0 = 0.f; s1 = 0.f;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) { s0 += red[0][r][cl]; s1 += red[1][r][cl]; }
+  for (int r = 0; r < kFinLanes; ++r) { s0 += red[0][r][cl]; s1 += red[1][r][cl]; }
   return true;
 }
 
 // Writes mean, invstd, scale = gamma*invstd, shift = beta - mean*scale, and folds the batch
-// statistics into the running ones (unbiased variance, torch convention). grid = ceil(C / 32).
+// statistics into the running ones (unbiased variance, torch convention). grid = ceil(C / kFinCh).
 __global__ __launch_bounds__(kBlock) void bn_finalize_fwd_kernel(const float* __restrict__ part, int n_part,
                                        const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* __restrict__ run_mean,
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_fwd_kernel(const float* __
                                        float* __restrict__ shift, long long M, int C, float eps, float momentum) {
   float s0, s1;
   if (!bn_sum_partials(part, n_part, C, s0, s1)) return;
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int c = blockIdx.x * kFinCh + (threadIdx.x % kFinCh);
   const float inv_m = 1.f / (float)M;
   const float mu = s0 * inv_m;
   const float var = fmaxf(s1 * inv_m - mu * mu, 0.f);
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_bwd_kernel(const float* __
                                        float* __restrict__ cK, float* __restrict__ c0, long long M, int C) {
   float s0, s1;
   if (!bn_sum_partials(part, n_part, C, s0, s1)) return;
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int c = blockIdx.x * kFinCh + (threadIdx.x % kFinCh);
   dbeta[c] = s0; dgamma[c] = s1;
   const float inv_m = 1.f / (float)M;
   const float a = gamma[c] * invstd[c];
@@ -266,7 +270,7 @@ DTF_API int dtf_bn_fwd_train(const void* x, const void* res, void* y, const floa
   const dim3 grid(nb, (C + 2047) / 2048);
   hipLaunchKernelGGL(bn_partial_kernel<0>, grid, dim3(kBlock), 0, stream, (const unsigned short*)x, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, workspace, nb, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb, gamma, beta,
                      run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y, M, C, relu);
@@ -295,7 +299,7 @@ DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float
   hipLaunchKernelGGL(bn_partial_kernel<1>, grid, dim3(kBlock), 0, stream, (const unsigned short*)x,
                      (const unsigned short*)dy, (const unsigned short*)y, mean, invstd, scale, shift, workspace, M, C,
                      relu);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, workspace, nb, gamma, mean,
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb, gamma, mean,
                      invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C);
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,

@@ -96,8 +96,11 @@ class Bottleneck(nn.Module):
             self.down_bn = BNAct(cout, relu=False)
 
     def forward(self, x):
-        idt = x if self.down is None else self.down_bn(self.down(x))
-        y = self.bn1(self.conv1(x))
+        # the alias xi carries the identity branch's gradient into conv1's data-gradient epilogue
+        c1 = self.conv1
+        y, xi = conv_ops.conv2d_fork(x, c1.weight, c1.stride, c1.padding)
+        idt = xi if self.down is None else self.down_bn(self.down(xi))
+        y = self.bn1(y)
         y = self.bn2(self.conv2(y))
         return self.bn3(self.conv3(y), residual=idt)   # relu(bn(conv) + identity) in one fused pass
 

@@ -77,7 +77,9 @@ class _ConvFn(torch.autograd.Function):
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_alias=None):
+        """``g_alias`` (fork variant only): gradient that arrived through the aliased input; it is
+        added to the data gradient inside the GEMM epilogue instead of by a separate add kernel."""
         x, w = ctx.saved_tensors
         N, C, H, W, K, KH, KW, OH, OW, stride, padding = ctx.geom
         if not gy.is_contiguous(memory_format=torch.channels_last):
@@ -98,12 +100,18 @@ class _ConvFn(torch.autograd.Function):
                 gw, want_w = lgw, False
         if want_x:
             gx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+            add = None
+            if (g_alias is not None and g_alias.dtype == gx.dtype and g_alias.shape == x.shape
+                    and g_alias.is_contiguous(memory_format=torch.channels_last)):
+                add, g_alias = g_alias.permute(0, 2, 3, 1), None
             if plain:
-                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, K, K, C, C)
+                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, K, K, C, C, add=add)
             else:
                 ex = _gemm.conv_geom(_gemm.CONV_DGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
-                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, KH * KW * K, K, KH * KW * C, C, extra=ex)
+                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, KH * KW * K, K, KH * KW * C, C, extra=ex, add=add)
             gx = gx.permute(0, 3, 1, 2)
+        if g_alias is not None and ctx.needs_input_grad[0]:
+            gx = g_alias if gx is None else gx + g_alias
         if want_w:
             gw = torch.empty((K, KH, KW, C), dtype=w.dtype, device=x.device)
             if plain:
@@ -113,6 +121,24 @@ class _ConvFn(torch.autograd.Function):
                 _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex)
             gw = gw.permute(0, 3, 1, 2)        # [K, C, KH, KW] with channels_last strides
         return gx, gw, None, None, None
+
+
+class _ConvForkFn(_ConvFn):
+    """``(conv(x, w), alias of x)``: the block input feeds both the first convolution and the identity
+    (or down-sampling) branch. Routing the second use through the alias hands its gradient to this
+    function's backward, which accumulates it in the epilogue of the data-gradient GEMM; autograd's
+    separate add kernel over the largest activations of the network disappears."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, auto=False):
+        y = _ConvFn.forward(ctx, x, w, stride, padding, auto)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, g_alias):
+        if gy is None:       # the convolution branch was unused
+            return g_alias, None, None, None, None
+        return _ConvFn.backward(ctx, gy, g_alias)
 
 
 def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -132,3 +158,14 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0) 
     if x.dtype != w.dtype:
         x = x.to(w.dtype)
     return F.conv2d(x, w, None, stride, padding)
+
+
+def conv2d_fork(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0):
+    """``(conv2d(x, w), x')`` where ``x'`` aliases ``x``: use ``x'`` for the other consumer of ``x`` (a
+    residual branch) so that the two gradients of ``x`` are summed inside the data-gradient GEMM."""
+    one = w.shape[2] == 1 and w.shape[3] == 1
+    backend = _backend if one else _backend_kxk
+    if (backend != "library" and stride in (1, 2) and _gemm_ok(x, w) and x.requires_grad and torch.is_grad_enabled()
+            and (stride == 1 or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0))):
+        return _ConvForkFn.apply(x, w, stride, padding, backend == "auto")
+    return conv2d(x, w, stride, padding), x

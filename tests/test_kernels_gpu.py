@@ -507,3 +507,29 @@ def test_gemm_single_and_double_buffered_loops_agree(stages):
                 assert torch.allclose(out.float(), ref, atol=0.5, rtol=2e-2), (stages, M, N, K)
     finally:
         lib.dtf_gemm_set_stages(0)
+
+
+@pytest.mark.gpu
+def test_conv_fork_accumulates_branch_gradient_in_epilogue():
+    from distributed_tensorflow_amd.ops import conv
+    torch.manual_seed(5)
+    x = torch.randn(4, 64, 14, 14, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(32, 64, 1, 1, device=DEV) * 0.1).bfloat16().contiguous(memory_format=torch.channels_last)
+    res = {}
+    for fork in (True, False):
+        x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        if fork:
+            y, xi = conv.conv2d_fork(x1, w1, 1, 0)
+        else:
+            y, xi = conv.conv2d(x1, w1, 1, 0), x1
+        out = y.float().square().sum() + (xi.float() * 3.0).sin().sum()
+        out.backward()
+        res[fork] = (x1.grad.float(), w1.grad.float())
+    ref_scale = float(res[False][0].abs().max())
+    assert torch.allclose(res[True][0], res[False][0], atol=0.02 * ref_scale, rtol=2e-2)
+    assert torch.allclose(res[True][1], res[False][1], atol=0.02 * float(res[False][1].abs().max()), rtol=2e-2)
+    # unused convolution branch: only the alias gradient flows
+    x1 = x.clone().requires_grad_(True)
+    _, xi = conv.conv2d_fork(x1, w, 1, 0)
+    xi.float().sum().backward()
+    assert torch.equal(x1.grad, torch.ones_like(x1))
