@@ -27,6 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops import dense as _dense
+from ..ops import pool as _pool
 
 
 def _to_np(t: torch.Tensor) -> np.ndarray:
@@ -260,7 +261,7 @@ class _Pool2D(Layer):
 
 class MaxPooling2D(_Pool2D):
     def forward(self, x):
-        return F.max_pool2d(x, self.pool_size, self.strides)
+        return _pool.max_pool2d(x, self.pool_size, self.strides)
 
 
 class AveragePooling2D(_Pool2D):

@@ -28,6 +28,7 @@ from ..api.model import Model
 from ..ops import conv as conv_ops
 from ..ops import dense as dense_ops
 from ..ops import norm as norm_ops
+from ..ops import pool as pool_ops
 
 
 class Conv(nn.Module):
@@ -164,7 +165,7 @@ class ResNet50(Model):
     def forward(self, x, logits: bool = False):
         x = self.prepare_input(x)
         x = self.stem_bn(self.stem(x))
-        x = F.max_pool2d(x, 3, 2, 1)
+        x = pool_ops.max_pool2d(x, 3, 2, 1)
         x = self.blocks(x)
         y = self.head(x)
         return y if logits else torch.softmax(y.float(), dim=-1)

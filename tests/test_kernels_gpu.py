@@ -533,3 +533,24 @@ def test_conv_fork_accumulates_branch_gradient_in_epilogue():
     _, xi = conv.conv2d_fork(x1, w, 1, 0)
     xi.float().sum().backward()
     assert torch.equal(x1.grad, torch.ones_like(x1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(2, 64, 112, 112, 3, 2, 1), (3, 16, 28, 28, 2, 2, 0), (2, 8, 13, 11, 3, 1, 1),
+                                 (1, 24, 9, 10, 3, 2, 0)])
+def test_max_pool_matches_torch(cfg):
+    from distributed_tensorflow_amd.ops import pool
+    N, C, H, W, k, s, p = cfg
+    torch.manual_seed(sum(cfg))
+    # relu-like data: many exact ties (zeros), where the first-maximum convention decides the gradient
+    x = torch.relu(torch.randn(N, C, H, W, device=DEV)).bfloat16().contiguous(memory_format=torch.channels_last)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y = pool.max_pool2d(x1, k, s, p)
+    yr = torch.nn.functional.max_pool2d(x2, k, s, p)
+    assert y.shape == yr.shape and torch.equal(y, yr)
+    gy = torch.randn_like(yr)
+    y.backward(gy)
+    yr.backward(gy)
+    assert torch.allclose(x1.grad.float(), x2.grad.float(), atol=2e-2, rtol=2e-2)
+    # windows that overlap (k > s) add gradients in fp32 in the own kernel: total mass is preserved
+    assert abs(float(x1.grad.float().sum()) - float(gy.float().sum())) < 0.02 * float(gy.float().abs().sum()) ** 0.5 + 1.0
