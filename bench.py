@@ -32,7 +32,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DTF_BENCH_BATCH", "256")), help="per-GPU batch")
     ap.add_argument("--image", type=int, default=224)
-    ap.add_argument("--bucket-mb", type=int, default=48)
+    ap.add_argument("--bucket-mb", type=int, default=16)
     ap.add_argument("--conv1x1", default=None, choices=[None, "auto", "gemm", "library"])
     ap.add_argument("--convkxk", default=None, choices=[None, "auto", "gemm", "library"])
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"], help="cpu is for plumbing tests only")
@@ -40,6 +40,17 @@ def main() -> int:
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and a.device == "gpu":
+        # started without a launcher: start one rank per GPU as child processes (nothing here has
+        # touched the GPU yet) and pass their exit code on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        return subprocess.call(cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
