@@ -126,6 +126,54 @@ __global__ __launch_bounds__(kBlock) void emb_segment_sum_kernel(const G* __rest
   }
 }
 
+// Dense table gradient from rows SORTED by id (sorted_ids ascending, perm[j] = row of g at sorted
+// position j). Equal ids are adjacent, so a run of them is summed in registers by one thread group
+// and written with a plain store: no atomic per element, which is what bounds the unsorted
+// scatter-add (about one atomic per gradient element, contended when an id repeats). A run is cut
+// at every kRunCut-th sorted position so that a very frequent id (padding, token type) is still
+// summed in parallel; only the pieces of such cut runs are combined with atomics.
+constexpr int kRunCut = 128;
+
+template <typename G>
+__global__ __launch_bounds__(kBlock) void emb_sorted_grad_kernel(const G* __restrict__ g,
+                                                                 const long long* __restrict__ sorted_ids,
+                                                                 const long long* __restrict__ perm,
+                                                                 float* __restrict__ dtable, long long n, int D,
+                                                                 long long row_base, long long n_rows) {
+  constexpr int V = Row<G>::V;
+  const int cpr = D / V;
+  const long long total = n * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long j = i / cpr;
+    const int c = (int)(i - j * cpr) * V;
+    const long long id = sorted_ids[j];
+    const bool head = j == 0 || sorted_ids[j - 1] != id;
+    if (!head && (j % kRunCut) != 0) continue;            // an earlier position owns this row
+    const long long loc = id - row_base;
+    if (loc < 0 || loc >= n_rows) continue;
+    long long end = (j / kRunCut + 1) * kRunCut;
+    if (end > n) end = n;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long k = j;
+    for (; k < end && sorted_ids[k] == id; ++k) {
+      float v[8];
+      Row<G>::ld(g + perm[k] * D + c, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += v[e];
+    }
+    const bool whole = head && (k == n || sorted_ids[k] != id);
+    float* dst = dtable + loc * D + c;
+    if (whole) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) dst[e] = acc[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) atomicAdd(dst + e, acc[e]);
+    }
+  }
+}
+
 // Optimizer update of the touched rows only. kind 0: SGD (p -= lr*g); 1: Adagrad (v += g^2,
 // p -= lr*g/(sqrt(v)+eps)); 2: Adam with per-row lazy moments (bias correction from hyper[1..2]).
 // hyper = {lr, bc1, bc2, eps, beta1, beta2, grad_scale, _}.
@@ -206,6 +254,23 @@ DTF_API int dtf_emb_scatter_add(const void* g, const long long* ids, float* dtab
     if (D % 4) return -1;
     hipLaunchKernelGGL((emb_scatter_add_kernel<float>), dim3(grid_for(n * (D / 4), kBlock)), dim3(kBlock), 0, stream,
                        (const float*)g, ids, dtable, n, D, row_base, n_rows, period_rows);
+  }
+  return (int)hipGetLastError();
+}
+
+// dtable (fp32 [n_rows, D]) must be zero on entry; sorted_ids / perm as produced by a stable sort of ids.
+DTF_API int dtf_emb_sorted_grad(const void* g, const long long* sorted_ids, const long long* perm, float* dtable,
+                                long long n, int D, long long row_base, long long n_rows, int g_dtype,
+                                hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (g_dtype == 1) {
+    if (D % 8) return -1;
+    hipLaunchKernelGGL((emb_sorted_grad_kernel<unsigned short>), dim3(grid_for(n * (D / 8), kBlock)), dim3(kBlock), 0,
+                       stream, (const unsigned short*)g, sorted_ids, perm, dtable, n, D, row_base, n_rows);
+  } else {
+    if (D % 4) return -1;
+    hipLaunchKernelGGL((emb_sorted_grad_kernel<float>), dim3(grid_for(n * (D / 4), kBlock)), dim3(kBlock), 0, stream,
+                       (const float*)g, sorted_ids, perm, dtable, n, D, row_base, n_rows);
   }
   return (int)hipGetLastError();
 }

@@ -67,6 +67,23 @@ def _scatter_add(g, ids, n_rows, row_base=0, period_rows=0):
     return out
 
 
+def _table_grad(g, ids, n_rows, row_base=0):
+    """fp32 [n_rows, D] gradient of a table from the row gradients ``g`` and their ``ids``: sort by id,
+    sum each run of equal ids in registers, store once (GPU); ``index_add_`` elsewhere."""
+    if not g.is_cuda:
+        return _scatter_add(g, ids, n_rows, row_base)
+    D = g.shape[1]
+    g = g.contiguous()
+    sorted_ids, perm = torch.sort(ids.reshape(-1).long(), stable=True)
+    out = torch.zeros(n_rows, D, dtype=torch.float32, device=g.device)
+    rc = _lib.kernels().dtf_emb_sorted_grad(_lib.ptr(g), _lib.ptr(sorted_ids), _lib.ptr(perm), _lib.ptr(out),
+                                            ctypes.c_longlong(g.shape[0]), D, ctypes.c_longlong(row_base),
+                                            ctypes.c_longlong(n_rows), _lib.dtype_code(g.dtype),
+                                            _lib.stream_ptr(g.device))
+    _lib.check(rc, "emb_sorted_grad")
+    return out
+
+
 class _EmbFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, ids, pos, typ, tt):
@@ -84,15 +101,21 @@ class _EmbFn(torch.autograd.Function):
         ids, tt = ctx.saved_tensors
         V, P, T, period, dt, has_tt = ctx.meta
         g2 = g.reshape(-1, g.shape[-1])
-        dtab = _scatter_add(g2, ids, V).to(dt) if ctx.needs_input_grad[0] else None
+        dtab = _table_grad(g2, ids, V).to(dt) if ctx.needs_input_grad[0] else None
         dpos = dtyp = None
         if P and ctx.needs_input_grad[2]:
-            d = _scatter_add(g2, None, period, period_rows=period)
-            dpos = torch.zeros(P, g.shape[-1], dtype=torch.float32, device=g.device)
+            # position j of every sequence takes pos[j]: the gradient is a sum over the batch axis
+            H = g.shape[-1]
+            if g2.is_cuda and g2.dtype == torch.bfloat16 and g2.shape[0] % period == 0:
+                from . import gemm as _gemm
+                d = _gemm.col_sum(g2.contiguous().view(-1, period * H)).view(period, H)
+            else:
+                d = _scatter_add(g2, None, period, period_rows=period)
+            dpos = torch.zeros(P, H, dtype=torch.float32, device=g.device)
             dpos[:period] = d
             dpos = dpos.to(dt)
         if T and ctx.needs_input_grad[3]:
-            dtyp = _scatter_add(g2, tt, T).to(dt)
+            dtyp = _table_grad(g2, tt, T).to(dt)
         return dtab, None, dpos, dtyp, None
 
 

@@ -554,3 +554,23 @@ def test_max_pool_matches_torch(cfg):
     assert torch.allclose(x1.grad.float(), x2.grad.float(), atol=2e-2, rtol=2e-2)
     # windows that overlap (k > s) add gradients in fp32 in the own kernel: total mass is preserved
     assert abs(float(x1.grad.float().sum()) - float(gy.float().sum())) < 0.02 * float(gy.float().abs().sum()) ** 0.5 + 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_embedding_table_grad_sorted_runs(dt):
+    """Long runs of one id (cut into pieces, combined with atomics) and singletons (plain stores)."""
+    from distributed_tensorflow_amd.ops import embedding as E
+    torch.manual_seed(11)
+    n, D, V = 5000, 64, 300
+    ids = torch.randint(0, V, (n,), device=DEV)
+    ids[:2000] = 3                        # a padding-like id: one run of > 2000 rows
+    ids[2000:2300] = V - 1                # the last row of the table, run crosses a cut
+    ids = ids[torch.randperm(n, device=DEV)]
+    g = torch.randn(n, D, device=DEV).to(dt)
+    out = E._table_grad(g, ids, V)
+    ref = torch.zeros(V, D, device=DEV, dtype=torch.float64).index_add_(0, ids, g.double())
+    torch.testing.assert_close(out.double(), ref, rtol=1e-3, atol=2e-2 if dt == torch.bfloat16 else 1e-3)
+    # shard-local: only rows [100, 200) are kept
+    out2 = E._table_grad(g, ids, 100, row_base=100)
+    torch.testing.assert_close(out2.double(), ref[100:200], rtol=1e-3, atol=2e-2 if dt == torch.bfloat16 else 1e-3)
