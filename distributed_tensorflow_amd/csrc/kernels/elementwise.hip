@@ -97,35 +97,56 @@ __global__ void rng_tick_kernel(unsigned long long* counter, unsigned long long 
   if (threadIdx.x == 0 && blockIdx.x == 0) *counter += inc;
 }
 
-// out[n] += sum_m g[m][n] for a row-major bf16 [M][N] matrix (N % 8 == 0); out is fp32 and
-// zeroed by the caller. Block = 32 column-chunks (256 columns) x 8 row lanes.
-__global__ __launch_bounds__(kBlock) void col_sum_kernel(const unsigned short* __restrict__ g, float* __restrict__ out,
+// Column sums of a row-major bf16 [M][N] matrix (N % 8 == 0), two deterministic stages:
+// stage 1: block (bx, by) sums rows [by*rpb, (by+1)*rpb) of 256 columns -> part[by][n]
+//          (32 column chunks x 8 row lanes per block, combined through LDS in a fixed order);
+// stage 2: out[n] = sum_by part[by][n]. With a single row block stage 1 writes `out` directly.
+__global__ __launch_bounds__(kBlock) void col_sum_kernel(const unsigned short* __restrict__ g, float* __restrict__ part,
                                                          int M, int N, long long ld, int rows_per_block) {
-  __shared__ float part[8][33][8];
+  __shared__ float red[8][33][8];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int n = blockIdx.x * 256 + tx * 8;
   const int mbeg = blockIdx.y * rows_per_block;
   const int mend = min(M, mbeg + rows_per_block);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (n < N)
-    for (int m = mbeg + ty; m < mend; m += 8) {
+  if (n < N) {
+    int m = mbeg + ty;
+    for (; m + 8 < mend; m += 16) {        // two loads in flight
+      float v[8], w[8];
+      ld8(g + (long long)m * ld + n, v);
+      ld8(g + (long long)(m + 8) * ld + n, w);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k] + w[k];
+    }
+    for (; m < mend; m += 8) {
       float v[8];
       ld8(g + (long long)m * ld + n, v);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += v[k];
     }
+  }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) part[ty][tx][k] = acc[k];
+  for (int k = 0; k < 8; ++k) red[ty][tx][k] = acc[k];
   __syncthreads();
   if (ty == 0 && n < N) {
+    float* dst = part + (long long)blockIdx.y * N + n;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) s += part[r][tx][k];
-      atomicAdd(out + n + k, s);
+      for (int r = 0; r < 8; ++r) s += red[r][tx][k];
+      dst[k] = s;
     }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void col_sum_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                int n_part, int N) {
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < n_part; ++p) s += part[(long long)p * N + n];
+  out[n] = s;
 }
 
 DTF_API int dtf_ew_bf16(int op, const void* a, const void* b, void* out, long long n, hipStream_t stream) {
@@ -170,14 +191,31 @@ DTF_API int dtf_rng_tick(void* counter, unsigned long long inc, hipStream_t stre
   return (int)hipGetLastError();
 }
 
-DTF_API int dtf_col_sum_bf16(const void* g, float* out, int M, int N, long long ld, hipStream_t stream) {
-  if (M <= 0 || N <= 0) return 0;
+// Number of row blocks (= fp32 rows of workspace needed) for an [M][N] column sum.
+DTF_API int dtf_col_sum_parts(int M, int N) {
   const int gx = (N + 255) / 256;
-  int gy = (2048 + gx - 1) / gx;
-  int rpb = (M + gy - 1) / gy;
-  if (rpb < 64) rpb = 64;
-  gy = (M + rpb - 1) / rpb;
-  hipLaunchKernelGGL(col_sum_kernel, dim3(gx, gy), dim3(kBlock), 0, stream, (const unsigned short*)g, out, M, N, ld,
-                     rpb);
+  int gy = (1024 + gx - 1) / gx;
+  const int by_rows = (M + 31) / 32;
+  if (gy > by_rows) gy = by_rows;
+  if (gy > 256) gy = 256;
+  if (gy < 1) gy = 1;
+  const int rpb = (M + gy - 1) / gy;
+  return (M + rpb - 1) / rpb;
+}
+
+// out: fp32 [N]; workspace: fp32 [dtf_col_sum_parts(M, N)][N] (unused when that is 1).
+DTF_API int dtf_col_sum_bf16(const void* g, float* out, int M, int N, long long ld, float* workspace,
+                             hipStream_t stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (N % 8) return -1;
+  const int gx = (N + 255) / 256;
+  const int gy = dtf_col_sum_parts(M, N);
+  const int rpb = (M + gy - 1) / gy;
+  if (gy > 1 && !workspace) return -2;
+  hipLaunchKernelGGL(col_sum_kernel, dim3(gx, gy), dim3(kBlock), 0, stream, (const unsigned short*)g,
+                     gy > 1 ? workspace : out, M, N, ld, rpb);
+  if (gy > 1)
+    hipLaunchKernelGGL(col_sum_finish_kernel, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, workspace, out,
+                       gy, N);
   return (int)hipGetLastError();
 }

@@ -81,7 +81,9 @@ _workspaces: dict[tuple, torch.Tensor] = {}
 
 
 def _workspace(device, numel: int) -> torch.Tensor:
-    key = (device.type, device.index)
+    # one workspace per stream: launches on one stream are ordered, launches on different streams
+    # (parameter-server service threads) must not share scratch memory
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < numel:
         ws = torch.empty(max(numel, 1 << 22), dtype=torch.float32, device=device)
@@ -250,11 +252,15 @@ def gelu_fwd(x: torch.Tensor) -> torch.Tensor:
 
 
 def col_sum(g: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
-    """Column sums of a row-major [M, N] matrix (the bias gradient)."""
+    """Column sums of a row-major [M, N] matrix (the bias gradient); deterministic two-stage reduction."""
     if g.is_cuda and g.dtype == torch.bfloat16 and g.shape[1] % 8 == 0 and g.stride(1) == 1 and g.data_ptr() % 16 == 0:
-        out = torch.zeros(g.shape[1], dtype=torch.float32, device=g.device)
-        rc = _lib.kernels().dtf_col_sum_bf16(_lib.ptr(g), _lib.ptr(out), g.shape[0], g.shape[1],
-                                             ctypes.c_longlong(g.stride(0)), _lib.stream_ptr(g.device))
+        lib = _lib.kernels()
+        M, N = g.shape
+        parts = lib.dtf_col_sum_parts(M, N)
+        out = torch.empty(N, dtype=torch.float32, device=g.device)
+        ws = _workspace(g.device, parts * N) if parts > 1 else None
+        rc = lib.dtf_col_sum_bf16(_lib.ptr(g), _lib.ptr(out), M, N, ctypes.c_longlong(g.stride(0)), _lib.ptr(ws),
+                                  _lib.stream_ptr(g.device))
         _lib.check(rc, "col_sum_bf16")
         return out.to(dtype)
     return g.float().sum(0).to(dtype)
