@@ -98,6 +98,35 @@ inline unsigned dropout_threshold(float p) {
   return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
 }
 
+// Sum over p of part[p * stride + c] for the 32 columns c = blockIdx.x * 32 + (tid & 31) of a
+// 256-thread block: the 8 partial-lanes (tid >> 5) each walk every 8th partial with four loads in
+// flight and are combined through LDS in a fixed order (bitwise reproducible). A one-thread-per-
+// column loop over hundreds of partials is latency-bound; this spreads it over the chip.
+// Returns true on the threads (partial-lane 0, column in range) that hold the sum in `s`.
+__device__ __forceinline__ bool partials_col_sum(const float* __restrict__ part, int n_part, long long stride, int n_cols,
+                                                 float& s) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float a = 0.f;
+  if (c < n_cols) {
+    int p = pl;
+    for (; p + 24 < n_part; p += 32) {
+      const float* q = part + (long long)p * stride + c;
+      const float x0 = q[0], x1 = q[8 * stride], x2 = q[16 * stride], x3 = q[24 * stride];
+      a += (x0 + x1) + (x2 + x3);
+    }
+    for (; p < n_part; p += 8) a += part[(long long)p * stride + c];
+  }
+  red[pl][cl] = a;
+  __syncthreads();
+  if (pl != 0 || c >= n_cols) return false;
+  s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) s += red[r][cl];
+  return true;
+}
+
 inline int grid_for(long long n_items, int per_block) {
   long long b = (n_items + per_block - 1) / per_block;
   if (b < 1) b = 1;

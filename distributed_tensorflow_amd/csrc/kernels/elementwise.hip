@@ -142,11 +142,9 @@ __global__ __launch_bounds__(kBlock) void col_sum_kernel(const unsigned short* _
 
 __global__ __launch_bounds__(kBlock) void col_sum_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                                 int n_part, int N) {
-  const int n = blockIdx.x * kBlock + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int p = 0; p < n_part; ++p) s += part[(long long)p * N + n];
-  out[n] = s;
+  float s;
+  if (!partials_col_sum(part, n_part, N, N, s)) return;
+  out[blockIdx.x * 32 + (threadIdx.x & 31)] = s;
 }
 
 DTF_API int dtf_ew_bf16(int op, const void* a, const void* b, void* out, long long n, hipStream_t stream) {
@@ -215,7 +213,6 @@ DTF_API int dtf_col_sum_bf16(const void* g, float* out, int M, int N, long long 
   hipLaunchKernelGGL(col_sum_kernel, dim3(gx, gy), dim3(kBlock), 0, stream, (const unsigned short*)g,
                      gy > 1 ? workspace : out, M, N, ld, rpb);
   if (gy > 1)
-    hipLaunchKernelGGL(col_sum_finish_kernel, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, workspace, out,
-                       gy, N);
+    hipLaunchKernelGGL(col_sum_finish_kernel, dim3((N + 31) / 32), dim3(kBlock), 0, stream, workspace, out, gy, N);
   return (int)hipGetLastError();
 }

@@ -179,13 +179,12 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const unsigned short* __
   }
 }
 
-// out[2][H]: column sums of part[n_part][2][H]; one thread per column pair index.
+// out[2][H]: column sums of part[n_part][2][H]; 32 columns per block (see partials_col_sum).
 __global__ __launch_bounds__(kBlock) void ln_bwd_finalize_kernel(const float* __restrict__ part, int n_part, int H,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * H) return;
-  float s = 0.f;
-  for (int p = 0; p < n_part; ++p) s += part[(long long)p * 2 * H + c];
+  float s;
+  if (!partials_col_sum(part, n_part, 2LL * H, 2 * H, s)) return;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   if (c < H) dgamma[c] = s; else dbeta[c - H] = s;
 }
 
@@ -317,8 +316,8 @@ DTF_API int dtf_ln_bwd(const void* x, const void* dy, const void* dres_in, const
   switch (ch) { case 1: LNB_D(1); break; case 2: LNB_D(2); break; default: LNB_D(4); }
 #undef LNB_D
 #undef LNB
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * H + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, part, nb, H,
-                     dgamma, dbeta);
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * H + 31) / 32), dim3(kBlock), 0, stream, part, nb, H, dgamma,
+                     dbeta);
   return (int)hipGetLastError();
 }
 
