@@ -1,0 +1,288 @@
+// Deep-pipelined bf16 GEMM for large compute-bound shapes (gfx950): C[M,N] = act(A[M,K] * B[N,K]^T + bias).
+//
+// The 128x128 kernel in gemm.hip reads 0.5 KiB of LDS per MFMA, which makes the LDS port as busy as
+// the matrix cores and caps it near a third of the dense peak. This kernel gives every wave a
+// 128 x 64 output (0.375 KiB of LDS per MFMA), runs one 256 x 256 x 64 tile per CU with 8 waves, and
+// never lets the memory pipeline drain:
+//   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4); the XOR swizzle that keeps the
+//     ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address, the LDS
+//     image of a DMA being lane-linear;
+//   * a K-tile is four half-tiles of 128 rows (A rows 0-127 / 128-255, B likewise) in one of two
+//     LDS buffers, and a wave's output is four 64 x 32 quadrants, one per half-tile pair, so the
+//     half-tiles are needed one phase after the other rather than all at once;
+//   * each of the 4 phases of a K-tile reads one quadrant's fragments, issues the DMA of ONE
+//     half-tile (three half-tiles stay in flight across the barriers: `s_waitcnt vmcnt(6)`, raw
+//     s_barrier, never a drain), then runs the quadrant's 16 MFMAs;
+//   * the waves of the two row groups run one barrier apart, so on every SIMD one wave issues
+//     MFMAs while the other reads LDS and issues DMA.
+// Hazards (phases counted globally, P = 4 * tile + phase): a half-tile last read in phase L is
+// overwritten by a DMA issued in phase >= L + 2; a DMA waited for in phase W is read in phase
+// >= W + 1. The issue order below (phase 0: B1 of tile t+1, 1: A1 of t+1, 2: A0 of t+2, 3: B0 of
+// t+2) and the read order (0: A0 B0, 1: B1, 2: A1, 3: none) satisfy both with a wait that leaves the
+// three newest half-tiles in flight.
+// The reference trains its dense layers through TensorFlow's CPU MatMul (reference initializer.py:16-18).
+#include "dtf_common.h"
+
+using namespace dtf;
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int kT256 = 512;
+constexpr int kHalfBytes = 128 * TK * 2;   // 16 KiB: 128 rows x 64 bf16
+constexpr int kBufBytes = 4 * kHalfBytes;  // A0 A1 B0 B1
+constexpr int kLds256 = 2 * kBufBytes;     // 128 KiB
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+struct G256Args {
+  const unsigned short* A;
+  const unsigned short* B;
+  unsigned short* C;
+  const void* bias;
+  long long lda, ldb, ldc;
+  int M, N, K;
+  int bias_dtype, act;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int swz256(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float gelu_erf256(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__global__ __launch_bounds__(kT256, 1) void gemm256_nt_kernel(G256Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 2, wc = wid & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // XCD-aware bijective block -> tile map (an XCD owns a contiguous range of tiles)
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, rem = nwg & 7;
+  const int vt = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (orig >> 3);
+  // inside an XCD's range walk groups of kGroupM tile rows column by column: the group's A panels and
+  // the current B panel stay in that XCD's L2
+  constexpr int kGroupM = 8;
+  const int group_sz = kGroupM * g.tiles_n;
+  const int gid = vt / group_sz, in_g = vt - gid * group_sz;
+  const int first_m = gid * kGroupM;
+  const int gm = min(g.tiles_m - first_m, kGroupM);
+  const int tm = first_m + in_g % gm, tn = in_g / gm;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int nt = g.K / TK;
+
+  // per-thread source offsets of its two DMA pieces in each of the four half-tiles (k0 = 0)
+  long long src_off[4][2];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const bool isA = w < 2;
+    const int h = w & 1;
+    const int rmax = (isA ? g.M : g.N) - 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = u * 512 + tid;
+      const int row = p >> 3, cl = p & 7;
+      const int cg = cl ^ ((row >> 1) & 7);
+      int gr = (isA ? m0 : n0) + h * 128 + row;
+      gr = gr > rmax ? rmax : gr;          // rows past the edge re-read the last row; never stored
+      src_off[w][u] = (long long)gr * (isA ? g.lda : g.ldb) + cg * 8;
+    }
+  }
+  const int dma_dst = wid * 1024;          // wave-uniform; the DMA adds lane * 16
+
+  auto issue = [&](int which, int tile) {  // which: 0 A0, 1 A1, 2 B0, 3 B1
+    const unsigned short* base = which < 2 ? g.A : g.B;
+    char* dst = smem + (tile & 1) * kBufBytes + which * kHalfBytes + dma_dst;
+    const long long k0 = (long long)tile * TK;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + src_off[which][0] + k0), (lds_ptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + src_off[which][1] + k0), (lds_ptr_t)(dst + 8192), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: tile 0 complete, A0 and B0 of tile 1 in flight
+  issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0);
+  if (nt > 1) {
+    issue(0, 1); issue(2, 1);
+    WAIT_VM(4);
+  } else {
+    WAIT_VM(0);
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // the two row groups run one barrier apart
+
+  bf16x8_t a[4][2], b0[2][2], b1[2][2];
+  const int arow = wr * 64 + fr;               // + i * 16, inside an A half-tile
+  const int brow = wc * 32 + fr;               // + j * 16, inside a B half-tile
+
+#define LOAD_A(H)                                                                              \
+  do {                                                                                         \
+    const char* hp = buf + (H) * kHalfBytes;                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)   \
+        a[i][ks] = *reinterpret_cast<const bf16x8_t*>(hp + swz256(arow + i * 16, ks * 4 + fq)); \
+  } while (0)
+#define LOAD_B(DST, H)                                                                         \
+  do {                                                                                         \
+    const char* hp = buf + (2 + (H)) * kHalfBytes;                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)   \
+        DST[j][ks] = *reinterpret_cast<const bf16x8_t*>(hp + swz256(brow + j * 16, ks * 4 + fq)); \
+  } while (0)
+#define MFMA_Q(QI, QJ, BR)                                                                     \
+  do {                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
+            acc[(QI) * 4 + i][(QJ) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(         \
+                BR[j][ks], a[i][ks], acc[(QI) * 4 + i][(QJ) * 2 + j], 0, 0, 0);                \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+  } while (0)
+  // issue the phase's half-tile when its tile exists; otherwise drain, because the counted wait only
+  // bounds what is in flight when every phase issues
+#define ISSUE_OR_DRAIN(WHICH, TILE)                                                            \
+  do {                                                                                         \
+    if ((TILE) < nt) { issue(WHICH, TILE); WAIT_VM(6); } else { WAIT_VM(0); }                  \
+  } while (0)
+
+  for (int t = 0; t < nt; ++t) {
+    const char* buf = smem + (t & 1) * kBufBytes;
+    // phase 0: quadrant (A0, B0)
+    LOAD_B(b0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    LOAD_A(0);
+    ISSUE_OR_DRAIN(3, t + 1);
+    __builtin_amdgcn_s_barrier();
+    WAIT_LGKM0();
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_Q(0, 0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // phase 1: quadrant (A0, B1)
+    LOAD_B(b1, 1);
+    ISSUE_OR_DRAIN(1, t + 1);
+    __builtin_amdgcn_s_barrier();
+    WAIT_LGKM0();
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_Q(0, 1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // phase 2: quadrant (A1, B1)
+    LOAD_A(1);
+    ISSUE_OR_DRAIN(0, t + 2);
+    __builtin_amdgcn_s_barrier();
+    WAIT_LGKM0();
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_Q(1, 1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // phase 3: quadrant (A1, B0), fragments already in registers
+    ISSUE_OR_DRAIN(2, t + 2);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_Q(1, 0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the other group's last barrier
+  WAIT_VM(0);
+  __syncthreads();
+
+  // ---- epilogue: bias + activation in fp32, each wave stages its four 64 x 32 quadrants in its own
+  // 16 KiB of LDS and writes 64-byte row segments with 16-byte stores
+  if (g.bias || g.act) {
+#pragma unroll
+    for (int qj = 0; qj < 2; ++qj)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + qj * 128 + wc * 32 + j * 16 + fq * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias && n < g.N) {
+          if (g.bias_dtype == 0) {
+            const f32x4 tb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.bias) + n);
+            bv[0] = tb[0]; bv[1] = tb[1]; bv[2] = tb[2]; bv[3] = tb[3];
+          } else {
+            const u16x4 tb = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(g.bias) + n);
+            bv[0] = bf16_to_f32(tb[0]); bv[1] = bf16_to_f32(tb[1]); bv[2] = bf16_to_f32(tb[2]); bv[3] = bf16_to_f32(tb[3]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[i][qj * 2 + j][r] + bv[r];
+            if (g.act == 1) v = fmaxf(v, 0.f);
+            else if (g.act == 2) v = gelu_erf256(v);
+            acc[i][qj * 2 + j][r] = v;
+          }
+      }
+  }
+  char* stage = smem + wid * 16384;
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+    for (int qj = 0; qj < 2; ++qj) {
+      char* blk = stage + (qi * 2 + qj) * 4096;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 v = acc[qi * 4 + i][qj * 2 + j];
+          u32x2 o;
+          o[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+          o[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          *reinterpret_cast<u32x2*>(blk + (i * 16 + fr) * 64 + j * 32 + fq * 8) = o;
+        }
+    }
+  // the staging region is private to the wave: its own LDS accesses are ordered by the waits the
+  // compiler places for them
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+    for (int qj = 0; qj < 2; ++qj) {
+      const char* blk = stage + (qi * 2 + qj) * 4096;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int idx = v * 64 + lane;
+        const int row = idx >> 2, c16 = idx & 3;
+        const int m = m0 + qi * 128 + wr * 64 + row;
+        const int n = n0 + qj * 128 + wc * 32 + c16 * 8;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(blk + row * 64 + c16 * 16);
+        if (m < g.M && n < g.N) *reinterpret_cast<u32x4*>(g.C + (long long)m * g.ldc + n) = val;
+      }
+    }
+}
+
+}  // namespace
+
+// C (bf16, row-major, ldc) = act(A[M,K] (lda) * B[N,K]^T (ldb) + bias). Requirements: K % 64 == 0,
+// N % 8 == 0, lda/ldb/ldc % 8 == 0, 16-byte aligned bases. act: 0 none, 1 relu, 2 gelu(erf).
+// Returns -9 when the shape does not qualify (the caller then uses dtf_gemm_bf16).
+DTF_API int dtf_gemm256_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, long long lda,
+                           long long ldb, long long ldc, int bias_dtype, int act, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (K % TK || N % 8 || lda % 8 || ldb % 8 || ldc % 8) return -9;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_nt_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kLds256);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  G256Args g;
+  g.A = (const unsigned short*)A; g.B = (const unsigned short*)B; g.C = (unsigned short*)C; g.bias = bias;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias_dtype = bias_dtype; g.act = act;
+  g.tiles_m = (M + TM - 1) / TM; g.tiles_n = (N + TN - 1) / TN;
+  hipLaunchKernelGGL(gemm256_nt_kernel, dim3(g.tiles_m * g.tiles_n), dim3(kT256), kLds256, stream, g);
+  return (int)hipGetLastError();
+}

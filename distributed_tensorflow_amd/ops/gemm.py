@@ -14,6 +14,7 @@ operands qualifies. Callers route everything else to the library GEMM.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -133,6 +134,39 @@ def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, s
     return out
 
 
+_big_tile = os.environ.get("DTF_GEMM256", "1") == "1"
+
+
+def set_big_tile(on: bool) -> None:
+    """Routes large NT products to the 256x256 deep-pipelined kernel (A/B measurements switch it off)."""
+    global _big_tile
+    _big_tile = bool(on)
+
+
+def _big_ok(M: int, N: int, K: int) -> bool:
+    # compute-bound shapes only: the 256x256 tile needs >= ~1 tile per CU and a k-loop worth pipelining
+    if not (_big_tile and K % 64 == 0 and K >= 256 and N >= 256 and M >= 512):
+        return False
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    waves = -(-tiles // _N_CU)
+    return tiles / (waves * _N_CU) >= 0.7          # one tile per CU at a time: a ragged last wave idles CUs
+
+
+def gemm256_nt(a: torch.Tensor, b: torch.Tensor, bias=None, activation=None, out=None) -> torch.Tensor:
+    """``act(a[M,K] @ b[N,K]^T + bias)`` on the 256x256x64 LDS-DMA kernel (``csrc/kernels/gemm256.hip``)."""
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    bias_dtype = _lib.dtype_code(bias.dtype) if bias is not None else 0
+    rc = _lib.kernels().dtf_gemm256_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(bias), M, N, K,
+                                       ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
+                                       ctypes.c_longlong(out.stride(0)), bias_dtype, _ACT[activation],
+                                       _lib.stream_ptr(a.device))
+    _lib.check(rc, "gemm256_nt")
+    return out
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, activation=None, out_dtype=torch.bfloat16, splits=None,
             out=None, dropout=None) -> torch.Tensor:
     """``dropout(act(a[M,K] @ b[N,K]^T + bias))``. ``dropout = (p, seed, offset_tensor)`` applies Philox
@@ -147,6 +181,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, activation=None, out_dt
         extra.nb1 = extra.nb2 = 1
         extra.drop_p, extra.drop_seed, extra.drop_off = float(dropout[0]), int(dropout[1]), dropout[2].data_ptr()
         splits = 1
+    elif (out_dtype == torch.bfloat16 and splits is None and _big_ok(a.shape[0], b.shape[0], a.shape[1])
+          and (out is None or (out.dtype == torch.bfloat16 and out.stride(1) == 1 and out.stride(0) % 8 == 0))
+          and (bias is None or (bias.numel() == b.shape[0] and bias.is_contiguous()))):
+        return gemm256_nt(a, b, bias, activation, out)
     return _launch(NT, a, b, a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0), bias, activation,
                    out_dtype, splits, out, extra=extra)
 
