@@ -626,6 +626,16 @@ struct GemmExtra {
   const void* drop_off;              // device pointer to the 64-bit Philox offset of this call
 };
 
+// Sums fp32 split-K slabs [splits][M][N] into C (bias, activation, conversion); shared with gemm256.hip.
+DTF_API int dtf_splitk_reduce(const float* W, void* C, const void* bias, int bias_dtype, int act, int out_fp32,
+                              int splits, int M, int N, long long ldc, hipStream_t stream) {
+  if (!W || !C || splits < 1 || N % 4) return -1;
+  const long long n4 = (long long)M * (N / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n4, 16), 1), dim3(kBlock), 0, stream, W, C, bias, bias_dtype,
+                     act, out_fp32, splits, M, N, ldc, 0LL);
+  return (int)hipGetLastError();
+}
+
 static int g_stages = 0;                 // 0 = automatic
 constexpr int kSingleStageTiles = 32;
 

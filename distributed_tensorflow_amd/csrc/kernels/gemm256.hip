@@ -1,4 +1,6 @@
-// Deep-pipelined bf16 GEMM for large compute-bound shapes (gfx950): C[M,N] = act(A[M,K] * B[N,K]^T + bias).
+// Deep-pipelined bf16 GEMM for large compute-bound shapes (gfx950): C[M,N] = act(op(A) * op(B) + bias) in
+// the three layouts of a dense layer: NT (forward, A[M,K] B[N,K]), NN (data gradient, A[M,K] B[K,N]) and
+// TN (weight gradient, A[K,M] B[K,N], with split-K because its contraction runs over the tokens).
 //
 // The 128x128 kernel in gemm.hip reads 0.5 KiB of LDS per MFMA, which makes the LDS port as busy as
 // the matrix cores and caps it near a third of the dense peak. This kernel gives every wave a
@@ -20,6 +22,8 @@
 // >= W + 1. The issue order below (phase 0: B1 of tile t+1, 1: A1 of t+1, 2: A0 of t+2, 3: B0 of
 // t+2) and the read order (0: A0 B0, 1: B1, 2: A1, 3: none) satisfy both with a wait that leaves the
 // three newest half-tiles in flight.
+// A k-major operand (rows = k) is staged as 64 k-rows of 256 bytes and its fragments are read with the
+// hardware-transposing ds_read_b64_tr_b16; the DMA source permutation is the XOR of that layout.
 // The reference trains its dense layers through TensorFlow's CPU MatMul (reference initializer.py:16-18).
 #include "dtf_common.h"
 
@@ -48,16 +52,45 @@ struct G256Args {
   int M, N, K;
   int bias_dtype, act;
   int tiles_m, tiles_n;
+  float* W;              // fp32 slabs [splits][M][N] when splits > 1
+  int k_per_split;       // multiple of TK
+  int splits;
 };
 
 __device__ __forceinline__ int swz256(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// k-major half-tile: 64 k-rows x 16 chunks of 16 bytes; chunk XOR for conflict-free transposed reads
+__device__ __forceinline__ int swz_t256(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
+
+typedef short s16x4_t256 __attribute__((ext_vector_type(4)));
+typedef short s16x8_t256 __attribute__((ext_vector_type(8)));
+
+// Fragment (16 rows x 32 k) of a half-tile: T = 0 rows are k-contiguous (ds_read_b128), T = 1 k-major
+// (two transposing 64-bit reads). row0 is a multiple of 16.
+template <int T>
+__device__ __forceinline__ bf16x8_t frag256(const char* half, int row0, int ks, int lane) {
+  if (T == 0) {
+    return *reinterpret_cast<const bf16x8_t*>(half + swz256(row0 + (lane & 15), ks * 4 + (lane >> 4)));
+  } else {
+    const int g4 = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
+    const int k = ks * 32 + 8 * g4 + q;
+    const int chunk = (row0 >> 3) + (p >> 1);
+    const int off = k * 256 + ((chunk ^ swz_t256(k)) << 4) + ((p & 1) << 3);
+    typedef __attribute__((address_space(3))) s16x4_t256* lp_t;
+    const s16x4_t256 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(half + off));
+    const s16x4_t256 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(half + off + 4 * 256));
+    const s16x8_t256 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
 
 __device__ __forceinline__ float gelu_erf256(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-__global__ __launch_bounds__(kT256, 1) void gemm256_nt_kernel(G256Args g) {
+template <int A_T, int B_T>
+__global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 2, wc = wid & 3;
@@ -77,31 +110,48 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_nt_kernel(G256Args g) {
   const int gm = min(g.tiles_m - first_m, kGroupM);
   const int tm = first_m + in_g % gm, tn = in_g / gm;
   const int m0 = tm * TM, n0 = tn * TN;
-  const int nt = g.K / TK;
+  const int split = blockIdx.y;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const int nt = (kend - kbeg) / TK;
 
-  // per-thread source offsets of its two DMA pieces in each of the four half-tiles (k0 = 0)
+  // per-thread source offsets of its two DMA pieces in each of the four half-tiles (first K-tile of
+  // this split) and the per-K-tile advance of each operand
   long long src_off[4][2];
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
     const bool isA = w < 2;
     const int h = w & 1;
-    const int rmax = (isA ? g.M : g.N) - 1;
+    const int T = isA ? A_T : B_T;
+    const long long ld = isA ? g.lda : g.ldb;
+    const int r0 = (isA ? m0 : n0) + h * 128;
+    const int rows = isA ? g.M : g.N;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int p = u * 512 + tid;
-      const int row = p >> 3, cl = p & 7;
-      const int cg = cl ^ ((row >> 1) & 7);
-      int gr = (isA ? m0 : n0) + h * 128 + row;
-      gr = gr > rmax ? rmax : gr;          // rows past the edge re-read the last row; never stored
-      src_off[w][u] = (long long)gr * (isA ? g.lda : g.ldb) + cg * 8;
+      if (T == 0) {
+        const int row = p >> 3, cl = p & 7;
+        const int cg = cl ^ ((row >> 1) & 7);
+        int gr = r0 + row;
+        gr = gr > rows - 1 ? rows - 1 : gr;      // rows past the edge re-read the last row; never stored
+        src_off[w][u] = (long long)gr * ld + kbeg + cg * 8;
+      } else {
+        const int k = p >> 4, cl = p & 15;
+        const int cg = cl ^ swz_t256(k);
+        int col = r0 + cg * 8;
+        col = col > rows - 8 ? rows - 8 : col;   // columns past the edge re-read the last chunk
+        src_off[w][u] = (long long)(kbeg + k) * ld + col;
+      }
     }
   }
+  const long long adv_a = A_T == 0 ? TK : (long long)TK * g.lda;
+  const long long adv_b = B_T == 0 ? TK : (long long)TK * g.ldb;
   const int dma_dst = wid * 1024;          // wave-uniform; the DMA adds lane * 16
 
   auto issue = [&](int which, int tile) {  // which: 0 A0, 1 A1, 2 B0, 3 B1
     const unsigned short* base = which < 2 ? g.A : g.B;
     char* dst = smem + (tile & 1) * kBufBytes + which * kHalfBytes + dma_dst;
-    const long long k0 = (long long)tile * TK;
+    const long long k0 = (long long)tile * (which < 2 ? adv_a : adv_b);
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + src_off[which][0] + k0), (lds_ptr_t)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + src_off[which][1] + k0), (lds_ptr_t)(dst + 8192), 16, 0, 0);
   };
@@ -124,20 +174,20 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_nt_kernel(G256Args g) {
   if (wr == 1) __builtin_amdgcn_s_barrier();   // the two row groups run one barrier apart
 
   bf16x8_t a[4][2], b0[2][2], b1[2][2];
-  const int arow = wr * 64 + fr;               // + i * 16, inside an A half-tile
-  const int brow = wc * 32 + fr;               // + j * 16, inside a B half-tile
+  const int arow = wr * 64;                    // + i * 16, inside an A half-tile
+  const int brow = wc * 32;                    // + j * 16, inside a B half-tile
 
 #define LOAD_A(H)                                                                              \
   do {                                                                                         \
     const char* hp = buf + (H) * kHalfBytes;                                                   \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)   \
-        a[i][ks] = *reinterpret_cast<const bf16x8_t*>(hp + swz256(arow + i * 16, ks * 4 + fq)); \
+        a[i][ks] = frag256<A_T>(hp, arow + i * 16, ks, lane);                                  \
   } while (0)
 #define LOAD_B(DST, H)                                                                         \
   do {                                                                                         \
     const char* hp = buf + (2 + (H)) * kHalfBytes;                                             \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)   \
-        DST[j][ks] = *reinterpret_cast<const bf16x8_t*>(hp + swz256(brow + j * 16, ks * 4 + fq)); \
+        DST[j][ks] = frag256<B_T>(hp, brow + j * 16, ks, lane);                                \
   } while (0)
 #define MFMA_Q(QI, QJ, BR)                                                                     \
   do {                                                                                         \
@@ -197,6 +247,26 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_nt_kernel(G256Args g) {
   if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the other group's last barrier
   WAIT_VM(0);
   __syncthreads();
+
+  if (g.splits > 1) {
+    // fp32 partial slab of this split: 16 bytes per lane (4 consecutive n); reduced by dtf_splitk_reduce
+    float* W = g.W + (long long)split * g.M * g.N;
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + qi * 128 + wr * 64 + i * 16 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int qj = 0; qj < 2; ++qj)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int n = n0 + qj * 128 + wc * 32 + j * 16 + fq * 4;
+            if (n < g.N) *reinterpret_cast<f32x4*>(W + (long long)m * g.N + n) = acc[qi * 4 + i][qj * 2 + j];
+          }
+      }
+    return;
+  }
 
   // ---- epilogue: bias + activation in fp32, each wave stages its four 64 x 32 quadrants in its own
   // 16 KiB of LDS and writes 64-byte row segments with 16-byte stores
@@ -265,24 +335,53 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_nt_kernel(G256Args g) {
 
 }  // namespace
 
-// C (bf16, row-major, ldc) = act(A[M,K] (lda) * B[N,K]^T (ldb) + bias). Requirements: K % 64 == 0,
-// N % 8 == 0, lda/ldb/ldc % 8 == 0, 16-byte aligned bases. act: 0 none, 1 relu, 2 gelu(erf).
-// Returns -9 when the shape does not qualify (the caller then uses dtf_gemm_bf16).
-DTF_API int dtf_gemm256_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, long long lda,
-                           long long ldb, long long ldc, int bias_dtype, int act, hipStream_t stream) {
+// defined in gemm.hip: sums fp32 slabs [splits][M][N] into C with bias / activation
+extern "C" int dtf_splitk_reduce(const float* W, void* C, const void* bias, int bias_dtype, int act, int out_fp32,
+                                 int splits, int M, int N, long long ldc, hipStream_t stream);
+
+// C (bf16, row-major, ldc) = act(op(A) * op(B) + bias). layout 0 NT: A[M,K] B[N,K]; 1 NN: A[M,K] B[K,N];
+// 2 TN: A[K,M] B[K,N]. Requirements: K % 64 == 0, N % 8 == 0 (M % 8 == 0 for TN), leading dimensions % 8 == 0,
+// 16-byte aligned bases, at least 8 rows / columns per operand. act: 0 none, 1 relu, 2 gelu(erf).
+// splits > 1: workspace holds splits * M * N floats. Returns -9 when the shape does not qualify
+// (the caller then uses dtf_gemm_bf16).
+DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                        long long lda, long long ldb, long long ldc, int bias_dtype, int act, int splits,
+                        void* workspace, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (K % TK || N % 8 || lda % 8 || ldb % 8 || ldc % 8) return -9;
+  if (K % TK || N % 8 || lda % 8 || ldb % 8 || ldc % 8 || M < 8 || N < 8) return -9;
+  if (layout == 2 && M % 8) return -9;
+  if (layout < 0 || layout > 2) return -1;
   static bool attr_set = false;
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_nt_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, kLds256);
-    if (e != hipSuccess) return (int)e;
+    const void* fns[3] = {reinterpret_cast<const void*>(gemm256_kernel<0, 0>),
+                          reinterpret_cast<const void*>(gemm256_kernel<0, 1>),
+                          reinterpret_cast<const void*>(gemm256_kernel<1, 1>)};
+    for (const void* f : fns) {
+      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLds256);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_set = true;
   }
+  if (splits < 1) splits = 1;
+  int kps = ((K + splits - 1) / splits + TK - 1) / TK * TK;
+  splits = (K + kps - 1) / kps;
+  if (splits > 1 && !workspace) return -3;
   G256Args g;
   g.A = (const unsigned short*)A; g.B = (const unsigned short*)B; g.C = (unsigned short*)C; g.bias = bias;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias_dtype = bias_dtype; g.act = act;
   g.tiles_m = (M + TM - 1) / TM; g.tiles_n = (N + TN - 1) / TN;
-  hipLaunchKernelGGL(gemm256_nt_kernel, dim3(g.tiles_m * g.tiles_n), dim3(kT256), kLds256, stream, g);
+  g.W = (float*)workspace; g.k_per_split = kps; g.splits = splits;
+  const dim3 grid(g.tiles_m * g.tiles_n, splits);
+  switch (layout) {
+    case 0: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid, dim3(kT256), kLds256, stream, g); break;
+    case 1: hipLaunchKernelGGL((gemm256_kernel<0, 1>), grid, dim3(kT256), kLds256, stream, g); break;
+    default: hipLaunchKernelGGL((gemm256_kernel<1, 1>), grid, dim3(kT256), kLds256, stream, g); break;
+  }
+  if (splits > 1) return dtf_splitk_reduce((const float*)workspace, C, bias, bias_dtype, act, 0, splits, M, N, ldc, stream);
   return (int)hipGetLastError();
+}
+
+DTF_API int dtf_gemm256_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, long long lda,
+                           long long ldb, long long ldc, int bias_dtype, int act, hipStream_t stream) {
+  return dtf_gemm256(0, A, B, C, bias, M, N, K, lda, ldb, ldc, bias_dtype, act, 1, nullptr, stream);
 }

@@ -152,19 +152,38 @@ def _big_ok(M: int, N: int, K: int) -> bool:
     return tiles / (waves * _N_CU) >= 0.7          # one tile per CU at a time: a ragged last wave idles CUs
 
 
-def gemm256_nt(a: torch.Tensor, b: torch.Tensor, bias=None, activation=None, out=None) -> torch.Tensor:
-    """``act(a[M,K] @ b[N,K]^T + bias)`` on the 256x256x64 LDS-DMA kernel (``csrc/kernels/gemm256.hip``)."""
-    M, K = a.shape
-    N = b.shape[0]
+def gemm256(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, bias=None, activation=None,
+            out=None, splits: int = 1) -> torch.Tensor:
+    """``act(op(a) @ op(b) + bias)`` on the 256x256x64 LDS-DMA kernel (``csrc/kernels/gemm256.hip``);
+    layouts as in this module (NT, NN, TN). ``splits`` > 1 splits the contraction (weight gradients)."""
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     bias_dtype = _lib.dtype_code(bias.dtype) if bias is not None else 0
-    rc = _lib.kernels().dtf_gemm256_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(bias), M, N, K,
-                                       ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
-                                       ctypes.c_longlong(out.stride(0)), bias_dtype, _ACT[activation],
-                                       _lib.stream_ptr(a.device))
-    _lib.check(rc, "gemm256_nt")
+    ws = _workspace(a.device, splits * M * N) if splits > 1 else None
+    rc = _lib.kernels().dtf_gemm256(layout, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(bias), M, N, K,
+                                    ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
+                                    ctypes.c_longlong(out.stride(0)), bias_dtype, _ACT[activation], splits,
+                                    _lib.ptr(ws), _lib.stream_ptr(a.device))
+    _lib.check(rc, "gemm256")
     return out
+
+
+def gemm256_nt(a: torch.Tensor, b: torch.Tensor, bias=None, activation=None, out=None) -> torch.Tensor:
+    return gemm256(NT, a, b, a.shape[0], b.shape[0], a.shape[1], bias, activation, out)
+
+
+def _big_splits(M: int, N: int, K: int) -> int:
+    """Split-K factor of a weight-gradient shaped product on the 256x256 kernel (0: do not use it)."""
+    if not (_big_tile and K % 64 == 0 and M >= 256 and N >= 256 and M % 8 == 0):
+        return 0
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles >= _N_CU:
+        waves = -(-tiles // _N_CU)
+        return 1 if tiles / (waves * _N_CU) >= 0.7 and K >= 256 else 0
+    if tiles < 24:          # the fp32 slabs of so many splits would outweigh the operands
+        return 0
+    splits = min(max(1, (2 * _N_CU) // tiles), K // 512)
+    return splits if splits >= 1 and tiles * splits >= _N_CU // 2 else 0
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, activation=None, out_dtype=torch.bfloat16, splits=None,
@@ -193,6 +212,9 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=N
     """``a[M,K] @ b[K,N]``."""
     if not (_ok2d(a) and _ok2d(b)) or a.shape[1] != b.shape[0]:
         raise ValueError("gemm_nn: operands must be 16-byte aligned bf16 [M,K] and [K,N]")
+    if (out_dtype == torch.bfloat16 and splits is None and _big_ok(a.shape[0], b.shape[1], a.shape[1])
+            and (out is None or (out.dtype == torch.bfloat16 and out.stride(1) == 1 and out.stride(0) % 8 == 0))):
+        return gemm256(NN, a, b, a.shape[0], b.shape[1], a.shape[1], out=out)
     return _launch(NN, a, b, a.shape[0], b.shape[1], a.shape[1], a.stride(0), b.stride(0), None, None, out_dtype,
                    splits, out)
 
@@ -201,6 +223,11 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=N
     """``a[K,M]^T @ b[K,N]``."""
     if not (_ok2d(a) and _ok2d(b)) or a.shape[0] != b.shape[0]:
         raise ValueError("gemm_tn: operands must be 16-byte aligned bf16 [K,M] and [K,N]")
+    if out_dtype == torch.bfloat16 and splits is None and (out is None or (out.dtype == torch.bfloat16 and
+                                                                          out.stride(1) == 1 and out.stride(0) % 8 == 0)):
+        sp = _big_splits(a.shape[1], b.shape[1], a.shape[0])
+        if sp:
+            return gemm256(TN, a, b, a.shape[1], b.shape[1], a.shape[0], out=out, splits=sp)
     return _launch(TN, a, b, a.shape[1], b.shape[1], a.shape[0], a.stride(0), b.stride(0), None, None, out_dtype,
                    splits, out)
 

@@ -607,3 +607,34 @@ def test_gemm256_operand_orientation():
     b = torch.randn(N, K, device=DEV).bfloat16()          # asymmetric: A = I gives C = B^T
     out = gemm.gemm256_nt(a, b)
     assert torch.equal(out, b.t().contiguous())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(256, 256, 64), (512, 768, 768), (1000, 520, 128), (304, 264, 192), (2048, 3072, 768)])
+def test_gemm256_nn_and_tn_layouts(shape):
+    from distributed_tensorflow_amd.ops import gemm
+    M, N, K = shape
+    torch.manual_seed(M * 3 + N + K)
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    bt = torch.randn(K, N, device=DEV).bfloat16()            # k-major B
+    ref = a.float() @ bt.float()
+    scale = max(1.0, float(ref.abs().max()))
+    out = gemm.gemm256(gemm.NN, a, bt, M, N, K)
+    assert torch.allclose(out.float() / scale, ref / scale, atol=1e-2, rtol=2e-2), float((out.float() - ref).abs().max())
+    at = a.t().contiguous()                                   # k-major A: [K, M]
+    for splits in (1, 3):
+        out = gemm.gemm256(gemm.TN, at, bt, M, N, K, splits=splits)
+        assert torch.allclose(out.float() / scale, ref / scale, atol=1e-2, rtol=2e-2), (splits, float((out.float() - ref).abs().max()))
+        assert torch.equal(out, gemm.gemm256(gemm.TN, at, bt, M, N, K, splits=splits))
+
+
+@pytest.mark.gpu
+def test_gemm256_weight_gradient_shape_with_split_k():
+    from distributed_tensorflow_amd.ops import gemm
+    torch.manual_seed(9)
+    T, N, K = 8192, 768, 512                                   # dW[N, K] = dY[T, N]^T @ X[T, K]
+    dy = torch.randn(T, N, device=DEV).bfloat16()
+    x = torch.randn(T, K, device=DEV).bfloat16()
+    out = gemm.gemm_tn(dy, x)
+    ref = dy.float().t() @ x.float()
+    assert torch.allclose(out.float(), ref, atol=0.02 * float(ref.abs().max()), rtol=2e-2)

@@ -23,6 +23,21 @@ def main():
                              ("lib", lambda: torch.matmul(a, b.t()))):
                 t = timeit(fn, iters=10, warmup=2) * 1e6
                 r[name + "_us"] = min(r.get(name + "_us", 1e30), t)
+        bt = b.t().contiguous()                       # [K, N]
+        gdy = torch.randn(M, N, device=DEV).bfloat16()  # weight-gradient shape: dW[N, K] = dY[M, N]^T @ X[M, K]
+        gemm.set_big_tile(True)
+        sp = gemm._big_splits(N, K, M)
+        for rnd in range(3):
+            gemm.set_big_tile(True)
+            r["nn256_us"] = min(r.get("nn256_us", 1e30), timeit(lambda: gemm.gemm256(gemm.NN, a, bt, M, N, K), iters=10, warmup=2) * 1e6)
+            if sp:
+                r["tn256_us"] = min(r.get("tn256_us", 1e30), timeit(lambda: gemm.gemm256(gemm.TN, gdy, a, N, K, M, splits=sp), iters=10, warmup=2) * 1e6)
+            gemm.set_big_tile(False)
+            r["nn128_us"] = min(r.get("nn128_us", 1e30), timeit(lambda: gemm.gemm_nn(a, bt), iters=10, warmup=2) * 1e6)
+            r["tn128_us"] = min(r.get("tn128_us", 1e30), timeit(lambda: gemm.gemm_tn(gdy, a), iters=10, warmup=2) * 1e6)
+            r["tnlib_us"] = min(r.get("tnlib_us", 1e30), timeit(lambda: torch.matmul(gdy.t(), a), iters=10, warmup=2) * 1e6)
+        gemm.set_big_tile(True)
+        r["tn_splits"] = sp
         fl = 2.0 * M * N * K
         for name in ("k256", "k128", "lib"):
             r[name + "_TF"] = fl / r[name + "_us"] / 1e6
