@@ -78,6 +78,11 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short
           ld8bf(y + r * C + c0, o);
 #pragma unroll
           for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+        } else if (relu == 3) {
+          // one mask byte per 8 channels, written by the forward pass (y holds the byte array)
+          const unsigned mb = reinterpret_cast<const unsigned char*>(y)[(r * C + c0) >> 3];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[k] = (mb >> k) & 1u ? g[k] : 0.f;
         } else if (relu == 2) {
           // no residual: the forward output was relu(fma(x, scale, shift)); recompute its sign from x
 #pragma unroll
@@ -184,7 +189,8 @@ __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(const unsigned sho
                                                               const unsigned short* __restrict__ res,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
-                                                              unsigned short* __restrict__ y, long long M, int C,
+                                                              unsigned short* __restrict__ y,
+                                                              unsigned char* __restrict__ mask, long long M, int C,
                                                               int relu) {
   const long long n8 = M * (C >> 3);
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -200,6 +206,12 @@ __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(const unsigned sho
       ld8bf(res + i * 8, r);
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] += r[k];
+    }
+    if (mask) {      // sign bits of the pre-activation: the backward pass reads 1 byte instead of 16
+      unsigned mb = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mb |= (v[k] > 0.f ? 1u : 0u) << k;
+      mask[i] = (unsigned char)mb;
     }
     if (relu) {
 #pragma unroll
@@ -233,6 +245,10 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(const unsigned sho
       ld8bf(y + i * 8, o);
 #pragma unroll
       for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+    } else if (relu == 3) {
+      const unsigned mb = reinterpret_cast<const unsigned char*>(y)[i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = (mb >> k) & 1u ? g[k] : 0.f;
     } else if (relu == 2) {
       float sa[8], sb[8];
       ld8f(scale + c, sa); ld8f(shift + c, sb);
@@ -262,7 +278,7 @@ DTF_API int dtf_bn_num_partials(long long M, int C) { return bn_partials_for(M, 
 // workspace: fp32 [n_partials * 2 * C]. stats: mean, invstd, scale, shift each [C] fp32.
 DTF_API int dtf_bn_fwd_train(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                              float* run_mean, float* run_var, float* mean, float* invstd, float* scale, float* shift,
-                             float* workspace, long long M, int C, float eps, float momentum, int relu,
+                             float* workspace, void* mask_out, long long M, int C, float eps, float momentum, int relu,
                              hipStream_t stream) {
   if (M <= 0 || C <= 0) return 0;
   if (C % 8) return -1;
@@ -273,7 +289,8 @@ DTF_API int dtf_bn_fwd_train(const void* x, const void* res, void* y, const floa
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb, gamma, beta,
                      run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
-                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y, M, C, relu);
+                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
+                     (unsigned char*)mask_out, M, C, relu);
   return (int)hipGetLastError();
 }
 
@@ -282,12 +299,15 @@ DTF_API int dtf_bn_fwd_apply(const void* x, const void* res, void* y, const floa
   if (M <= 0 || C <= 0) return 0;
   if (C % 8) return -1;
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
-                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y, M, C, relu);
+                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
+                     (unsigned char*)nullptr, M, C, relu);
   return (int)hipGetLastError();
 }
 
 // coef: fp32 [3 * C] scratch (A, K, C0). relu: 0 none, 1 mask from the saved output y, 2 mask recomputed
-// from x with the forward's scale/shift (layers without a residual input; y is not read at all).
+// from x with the forward's scale/shift (layers without a residual input; y is not read at all), 3 mask
+// bits written by dtf_bn_fwd_train (y points to that byte array: M * C / 8 bytes).
+// workspace (fp32 partial sums) and mask_out: see dtf_bn_num_partials.
 DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* mean,
                        const float* invstd, const float* scale, const float* shift, void* dx, void* dres,
                        float* dgamma, float* dbeta, float* coef, float* workspace, long long M, int C, int relu,

@@ -44,15 +44,19 @@ class _BNActFn(torch.autograd.Function):
         ws = _scratch(dev, nb * 2 * C)
         if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
             residual = residual.contiguous(memory_format=torch.channels_last)
+        # relu mask for backward: with a residual the sign of the pre-activation cannot be recomputed
+        # from x alone, so the forward pass writes it as one bit per element (1/16 of re-reading y);
+        # without a residual it is recomputed from x and nothing is kept
+        ctx.has_res = residual is not None
+        ctx.relu = 0 if not relu else (3 if residual is not None else 2)
+        mask = torch.empty(M * C // 8, dtype=torch.uint8, device=dev) if ctx.relu == 3 else None
         rc = lib.dtf_bn_fwd_train(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta),
                                   _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
-                                  _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), ctypes.c_longlong(M), C,
-                                  ctypes.c_float(eps), ctypes.c_float(momentum), int(relu), _lib.stream_ptr(dev))
+                                  _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), _lib.ptr(mask),
+                                  ctypes.c_longlong(M), C, ctypes.c_float(eps), ctypes.c_float(momentum), int(relu),
+                                  _lib.stream_ptr(dev))
         _lib.check(rc, "bn_fwd_train")
-        ctx.has_res = residual is not None
-        # relu mask: from the saved output when a residual took part, else recomputed from x (y is not kept)
-        ctx.relu = 0 if not relu else (1 if residual is not None else 2)
-        ctx.save_for_backward(x, y if ctx.relu == 1 else None, gamma, stats)
+        ctx.save_for_backward(x, mask, gamma, stats)
         return y
 
     @staticmethod
