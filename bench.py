@@ -4,7 +4,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Configuration (the one BASELINE.json names): ResNet-50, synthetic 224x224 images, bf16 compute,
+Configuration (the headline one): ResNet-50, synthetic 224x224 images, bf16 compute,
 decentralized keras-style mirrored all-reduce, one process per GPU over RCCL. Weak scaling: the
 per-GPU batch is fixed, the global batch grows with N. A step is forward + backward + bucketed
 gradient all-reduce + optimizer update; nothing is skipped inside the timed region.
