@@ -6,19 +6,62 @@ buffer through leading dimensions and two-level batch strides (batch, head), so 
 split / transpose copies are made. The scale ``1/sqrt(hd)`` and the optional additive
 key-padding bias are fused into the softmax kernel.
 
-Scores are materialised (``[B, nh, S, S]`` bf16): at the sequence length of the BERT-base
-configuration (512) that is 6 MiB per sample, far inside 288 GB of HBM, and keeps every FLOP on
-the GEMM kernel.
+Two paths: head dimension 64 with ``S % 128 == 0`` (the BERT-base configuration) runs the fused
+flash-style kernels of ``csrc/kernels/flash_attn.hip`` (scores never leave registers; backward
+recomputes the probabilities from the stored log-sum-exp). Other shapes materialise the scores
+(``[B, nh, S, S]`` bf16) and run the batched GEMM + fused softmax kernels. ``set_flash(False)`` or
+``DTF_FLASH=0`` forces the second path.
 """
 from __future__ import annotations
 
 import ctypes
 import math
+import os
 
 import torch
 
 from . import _lib
 from . import gemm as G
+
+
+_flash = os.environ.get("DTF_FLASH", "1") == "1"
+
+
+def set_flash(on: bool) -> None:
+    global _flash
+    _flash = bool(on)
+
+
+def _flash_ok(qkv: torch.Tensor) -> bool:
+    B, S, three, nh, hd = qkv.shape
+    return _flash and hd == 64 and S % 128 == 0 and S >= 128
+
+
+class _FlashFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, bias):
+        B, S, _, nh, hd = qkv.shape
+        out = torch.empty(B, S, nh, hd, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, nh, S, dtype=torch.float32, device=qkv.device)
+        rc = _lib.kernels().dtf_flash_attn_fwd(_lib.ptr(qkv), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(lse), B, S, nh, hd,
+                                               ctypes.c_float(1.0 / math.sqrt(hd)), _lib.stream_ptr(qkv.device))
+        _lib.check(rc, "flash_attn_fwd")
+        ctx.save_for_backward(qkv, bias if bias is not None else lse, out, lse)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, bias, out, lse = ctx.saved_tensors
+        B, S, _, nh, hd = qkv.shape
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty(B, nh, S, dtype=torch.float32, device=qkv.device)
+        rc = _lib.kernels().dtf_flash_attn_bwd(_lib.ptr(qkv), _lib.ptr(bias if ctx.has_bias else None), _lib.ptr(out),
+                                               _lib.ptr(lse), _lib.ptr(dout), _lib.ptr(delta), _lib.ptr(dqkv), B, S, nh,
+                                               hd, ctypes.c_float(1.0 / math.sqrt(hd)), _lib.stream_ptr(qkv.device))
+        _lib.check(rc, "flash_attn_bwd")
+        return dqkv, None
 
 
 def _fast(qkv: torch.Tensor) -> bool:
@@ -96,6 +139,8 @@ def self_attention(qkv: torch.Tensor, key_bias: torch.Tensor | None = None) -> t
     if _fast(qkv):
         if key_bias is not None:
             key_bias = key_bias.float().contiguous()
+        if _flash_ok(qkv):
+            return _FlashFn.apply(qkv, key_bias)
         return _AttnFn.apply(qkv, key_bias)
     B, S, _, nh, hd = qkv.shape
     q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).float() for i in range(3))
