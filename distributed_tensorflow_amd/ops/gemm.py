@@ -182,7 +182,7 @@ def _big_splits(M: int, N: int, K: int) -> int:
         return 1 if tiles / (waves * _N_CU) >= 0.7 and K >= 256 else 0
     if tiles < 24:          # the fp32 slabs of so many splits would outweigh the operands
         return 0
-    splits = min(max(1, (2 * _N_CU) // tiles), K // 512)
+    splits = min(max(1, _N_CU // tiles), K // 512)     # one full wave of tiles: fewer fp32 slabs to reduce
     return splits if splits >= 1 and tiles * splits >= _N_CU // 2 else 0
 
 
