@@ -52,6 +52,7 @@ struct G256Args {
   int M, N, K;
   int bias_dtype, act;
   int tiles_m, tiles_n;
+  const unsigned short* Cin;   // optional bf16 tensor (indexed like C) added to the result
   float* W;              // fp32 slabs [splits][M][N] when splits > 1
   int k_per_split;       // multiple of TK
   int splits;
@@ -315,20 +316,42 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
         }
     }
   // the staging region is private to the wave: its own LDS accesses are ordered by the waits the
-  // compiler places for them
+  // compiler places for them. The accumulate input is fetched for a whole quadrant before it is used,
+  // so that its 4 loads per lane are in flight together (one block per CU: nothing else hides them).
 #pragma unroll
   for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
     for (int qj = 0; qj < 2; ++qj) {
       const char* blk = stage + (qi * 2 + qj) * 4096;
+      u32x4 ci[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int idx = v * 64 + lane;
         const int row = idx >> 2, c16 = idx & 3;
         const int m = m0 + qi * 128 + wr * 64 + row;
         const int n = n0 + qj * 128 + wc * 32 + c16 * 8;
-        const u32x4 val = *reinterpret_cast<const u32x4*>(blk + row * 64 + c16 * 16);
-        if (m < g.M && n < g.N) *reinterpret_cast<u32x4*>(g.C + (long long)m * g.ldc + n) = val;
+        ci[v] = u32x4{0u, 0u, 0u, 0u};
+        if (g.Cin && m < g.M && n < g.N) ci[v] = *reinterpret_cast<const u32x4*>(g.Cin + (long long)m * g.ldc + n);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int idx = v * 64 + lane;
+        const int row = idx >> 2, c16 = idx & 3;
+        const int m = m0 + qi * 128 + wr * 64 + row;
+        const int n = n0 + qj * 128 + wc * 32 + c16 * 8;
+        u32x4 val = *reinterpret_cast<const u32x4*>(blk + row * 64 + c16 * 16);
+        if (m < g.M && n < g.N) {
+          if (g.Cin) {
+            // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(ci[v][e] << 16);
+              const float hi = __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(ci[v][e] & 0xffff0000u);
+              val[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+            }
+          }
+          *reinterpret_cast<u32x4*>(g.C + (long long)m * g.ldc + n) = val;
+        }
       }
     }
 }
@@ -342,11 +365,11 @@ extern "C" int dtf_splitk_reduce(const float* W, void* C, const void* bias, int 
 // C (bf16, row-major, ldc) = act(op(A) * op(B) + bias). layout 0 NT: A[M,K] B[N,K]; 1 NN: A[M,K] B[K,N];
 // 2 TN: A[K,M] B[K,N]. Requirements: K % 64 == 0, N % 8 == 0 (M % 8 == 0 for TN), leading dimensions % 8 == 0,
 // 16-byte aligned bases, at least 8 rows / columns per operand. act: 0 none, 1 relu, 2 gelu(erf).
-// splits > 1: workspace holds splits * M * N floats. Returns -9 when the shape does not qualify
+// splits > 1: workspace holds splits * M * N floats. cin: optional bf16 tensor laid out like C, added to the result. Returns -9 when the shape does not qualify
 // (the caller then uses dtf_gemm_bf16).
 DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                         long long lda, long long ldb, long long ldc, int bias_dtype, int act, int splits,
-                        void* workspace, hipStream_t stream) {
+                        void* workspace, const void* cin, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (K % TK || N % 8 || lda % 8 || ldb % 8 || ldc % 8 || M < 8 || N < 8) return -9;
   if (layout == 2 && M % 8) return -9;
@@ -362,7 +385,7 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
     }
     attr_set = true;
   }
-  if (splits < 1) splits = 1;
+  if (splits < 1 || cin) splits = 1;               // slabs do not carry the accumulate input
   int kps = ((K + splits - 1) / splits + TK - 1) / TK * TK;
   splits = (K + kps - 1) / kps;
   if (splits > 1 && !workspace) return -3;
@@ -370,7 +393,7 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
   g.A = (const unsigned short*)A; g.B = (const unsigned short*)B; g.C = (unsigned short*)C; g.bias = bias;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias_dtype = bias_dtype; g.act = act;
   g.tiles_m = (M + TM - 1) / TM; g.tiles_n = (N + TN - 1) / TN;
-  g.W = (float*)workspace; g.k_per_split = kps; g.splits = splits;
+  g.W = (float*)workspace; g.k_per_split = kps; g.splits = splits; g.Cin = (const unsigned short*)cin;
   const dim3 grid(g.tiles_m * g.tiles_n, splits);
   switch (layout) {
     case 0: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid, dim3(kT256), kLds256, stream, g); break;
@@ -383,5 +406,5 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
 
 DTF_API int dtf_gemm256_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, long long lda,
                            long long ldb, long long ldc, int bias_dtype, int act, hipStream_t stream) {
-  return dtf_gemm256(0, A, B, C, bias, M, N, K, lda, ldb, ldc, bias_dtype, act, 1, nullptr, stream);
+  return dtf_gemm256(0, A, B, C, bias, M, N, K, lda, ldb, ldc, bias_dtype, act, 1, nullptr, nullptr, stream);
 }

@@ -78,10 +78,12 @@ class EncoderLayer(nn.Module):
 
     def forward(self, x, key_bias=None):
         B, S, H = x.shape
-        qkv = self.qkv(x).view(B, S, 3, self.heads, H // self.heads)
-        ctxv = attn_ops.self_attention(qkv, key_bias).view(B, S, H)
-        x = self.ln1(self.proj(ctxv), residual=x)
-        return self.ln2(self.ffn2(self.ffn1(x)), residual=x)
+        # the aliases carry the residual branches' gradients into the data-gradient GEMM epilogues
+        qkv, xr = dense_ops.linear_fork(x, self.qkv.weight, self.qkv.bias)
+        ctxv = attn_ops.self_attention(qkv.view(B, S, 3, self.heads, H // self.heads), key_bias).view(B, S, H)
+        x = self.ln1(self.proj(ctxv), residual=xr)
+        f, xr = dense_ops.linear_fork(x, self.ffn1.weight, self.ffn1.bias, "gelu")
+        return self.ln2(self.ffn2(f), residual=xr)
 
 
 class Bert(Model):

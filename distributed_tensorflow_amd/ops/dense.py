@@ -55,7 +55,9 @@ class _LinearFn(torch.autograd.Function):
         return y.reshape(*x.shape[:-1], w.shape[0])
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_alias=None):
+        """``g_alias`` (fork variant): gradient that arrived through the aliased input; added to the data
+        gradient inside the GEMM epilogue."""
         x2, w, saved = ctx.saved_tensors
         g = gy.reshape(-1, gy.shape[-1])
         if ctx.drop is not None:
@@ -65,14 +67,38 @@ class _LinearFn(torch.autograd.Function):
         elif ctx.activation == "gelu":
             g = _gemm.gelu_bwd(g, saved)
         g = g.contiguous()
-        gx = _gemm.gemm_nn(g, w) if ctx.needs_input_grad[0] else None     # [M, K]
+        gx = None
+        if ctx.needs_input_grad[0]:
+            add = None
+            if g_alias is not None and g_alias.dtype == torch.bfloat16 and g_alias.is_contiguous() \
+                    and g_alias.data_ptr() % 16 == 0:
+                add, g_alias = g_alias.reshape(-1, g_alias.shape[-1]), None
+            gx = _gemm.gemm_nn(g, w, add=add)                               # [M, K]
         gw = _gemm.gemm_tn(g, x2) if ctx.needs_input_grad[1] else None    # [N, K]
         gb = None
         if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
             gb = _gemm.col_sum(g, dtype=ctx.bias_dtype)
         if gx is not None:
             gx = gx.reshape(ctx.x_shape)
+            if g_alias is not None:
+                gx = gx + g_alias
         return gx, gw, gb, None, None
+
+
+class _LinearForkFn(_LinearFn):
+    """``(linear(x), alias of x)``: when ``x`` also feeds a residual branch, routing that use through the
+    alias hands its gradient to this backward, which accumulates it in the data-gradient GEMM's
+    epilogue instead of leaving the sum to a separate add kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, activation, drop_p=0.0):
+        return _LinearFn.forward(ctx, x, w, b, activation, drop_p), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, g_alias):
+        if gy is None:
+            return g_alias, None, None, None, None
+        return _LinearFn.backward(ctx, gy, g_alias)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
@@ -88,3 +114,12 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = No
     y = F.linear(x, weight, bias.to(weight.dtype) if bias is not None else None)
     y = _act_fwd(y, activation)
     return F.dropout(y, p, True) if p > 0.0 else y
+
+
+def linear_fork(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
+                activation: str | None = None):
+    """``(linear(x, ...), x')`` with ``x'`` an alias of ``x`` for its other consumer (a residual branch)."""
+    if (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and _gemm.supported(x, weight)
+            and x.requires_grad and torch.is_grad_enabled()):
+        return _LinearForkFn.apply(x, weight, bias, activation, 0.0)
+    return linear(x, weight, bias, activation), x

@@ -153,7 +153,7 @@ def _big_ok(M: int, N: int, K: int) -> bool:
 
 
 def gemm256(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, bias=None, activation=None,
-            out=None, splits: int = 1) -> torch.Tensor:
+            out=None, splits: int = 1, add: torch.Tensor | None = None) -> torch.Tensor:
     """``act(op(a) @ op(b) + bias)`` on the 256x256x64 LDS-DMA kernel (``csrc/kernels/gemm256.hip``);
     layouts as in this module (NT, NN, TN). ``splits`` > 1 splits the contraction (weight gradients)."""
     if out is None:
@@ -163,7 +163,7 @@ def gemm256(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: in
     rc = _lib.kernels().dtf_gemm256(layout, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(bias), M, N, K,
                                     ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
                                     ctypes.c_longlong(out.stride(0)), bias_dtype, _ACT[activation], splits,
-                                    _lib.ptr(ws), _lib.stream_ptr(a.device))
+                                    _lib.ptr(ws), _lib.ptr(add), _lib.stream_ptr(a.device))
     _lib.check(rc, "gemm256")
     return out
 
@@ -208,13 +208,22 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, activation=None, out_dt
                    out_dtype, splits, out, extra=extra)
 
 
-def gemm_nn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=None, out=None) -> torch.Tensor:
-    """``a[M,K] @ b[K,N]``."""
+def gemm_nn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=None, out=None,
+            add: torch.Tensor | None = None) -> torch.Tensor:
+    """``a[M,K] @ b[K,N] (+ add)``; ``add`` is a contiguous bf16 ``[M, N]`` tensor accumulated in the epilogue."""
     if not (_ok2d(a) and _ok2d(b)) or a.shape[1] != b.shape[0]:
         raise ValueError("gemm_nn: operands must be 16-byte aligned bf16 [M,K] and [K,N]")
+    if add is not None:
+        if (add.dtype != torch.bfloat16 or tuple(add.shape) != (a.shape[0], b.shape[1]) or not add.is_contiguous()
+                or add.data_ptr() % 16 or out_dtype != torch.bfloat16 or out is not None):
+            raise ValueError("gemm_nn: add= needs a contiguous 16-byte aligned bf16 [M, N] tensor")
     if (out_dtype == torch.bfloat16 and splits is None and _big_ok(a.shape[0], b.shape[1], a.shape[1])
             and (out is None or (out.dtype == torch.bfloat16 and out.stride(1) == 1 and out.stride(0) % 8 == 0))):
-        return gemm256(NN, a, b, a.shape[0], b.shape[1], a.shape[1], out=out)
+        return gemm256(NN, a, b, a.shape[0], b.shape[1], a.shape[1], out=out, add=add)
+    if add is not None:
+        M, N, K = a.shape[0], b.shape[1], a.shape[1]
+        res = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+        return gemm_raw(NN, a, b, res, M, N, K, a.stride(0), b.stride(0), N, add=add)
     return _launch(NN, a, b, a.shape[0], b.shape[1], a.shape[1], a.stride(0), b.stride(0), None, None, out_dtype,
                    splits, out)
 

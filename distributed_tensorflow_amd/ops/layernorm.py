@@ -39,7 +39,7 @@ class _LNFn(torch.autograd.Function):
         rows = x.numel() // H
         dev = x.device
         y = torch.empty_like(x)
-        s = torch.empty_like(x) if (want_sum and res is not None) else None
+        s = torch.empty_like(x) if res is not None else None   # x + res, written by the kernel: backward's input
         stats = torch.empty(rows, 2, dtype=torch.float32, device=dev)
         if res is not None:
             res = res.contiguous()
@@ -47,12 +47,7 @@ class _LNFn(torch.autograd.Function):
                                        _lib.ptr(s), _lib.ptr(stats), ctypes.c_longlong(rows), H, ctypes.c_float(eps),
                                        _lib.dtype_code(gamma.dtype), _lib.stream_ptr(dev))
         _lib.check(rc, "ln_fwd")
-        if res is None:
-            xin = x
-        elif s is not None:
-            xin = s
-        else:
-            xin = x + res
+        xin = x if res is None else s
         ctx.save_for_backward(xin, gamma, stats)
         ctx.has_res = res is not None
         ctx.want_sum = want_sum

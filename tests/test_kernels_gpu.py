@@ -679,3 +679,25 @@ def test_flash_attention_matches_fp32_reference(B, S, nh, masked):
     assert float((gf - x.grad).abs().max()) < 0.03 * gs + 2e-2, (float((gf - x.grad).abs().max()), gs)
     # at least as close to fp32 as the unfused bf16 path is, within a factor
     assert float((gf - x.grad).abs().mean()) <= 2.0 * float((gu - x.grad).abs().mean()) + 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [96, 4096])        # 128x128 kernel / 256x256 kernel data-gradient paths
+def test_linear_fork_accumulates_residual_gradient(M):
+    from distributed_tensorflow_amd.ops import dense
+    torch.manual_seed(M)
+    K, N = 512, 768
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    w = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
+    b = torch.randn(N, device=DEV).bfloat16()
+    res = {}
+    for fork in (True, False):
+        x1, w1, b1 = (t.clone().requires_grad_(True) for t in (x, w, b))
+        if fork:
+            y, xi = dense.linear_fork(x1, w1, b1, "gelu")
+        else:
+            y, xi = dense.linear(x1, w1, b1, "gelu"), x1
+        (y.float().square().sum() * 1e-2 + (xi.float() * 2.0).cos().sum()).backward()
+        res[fork] = [t.grad.float() for t in (x1, w1, b1)]
+    for a, r in zip(res[True], res[False]):
+        assert torch.allclose(a, r, atol=0.03 * float(r.abs().max()) + 1e-3, rtol=3e-2)
