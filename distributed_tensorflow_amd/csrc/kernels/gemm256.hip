@@ -35,7 +35,8 @@ constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int kT256 = 512;
 constexpr int kHalfBytes = 128 * TK * 2;   // 16 KiB: 128 rows x 64 bf16
 constexpr int kBufBytes = 4 * kHalfBytes;  // A0 A1 B0 B1
-constexpr int kLds256 = 2 * kBufBytes;     // 128 KiB
+constexpr int kLds256 = 2 * kBufBytes;     // 128 KiB of operand buffers
+constexpr int kLdsAll = kLds256 + 8 * 4096;  // + 4 KiB of epilogue staging per wave = the CU's 160 KiB
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -97,86 +98,82 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
   const int wr = wid >> 2, wc = wid & 3;
   const int fr = lane & 15, fq = lane >> 4;
 
-  // XCD-aware bijective block -> tile map (an XCD owns a contiguous range of tiles)
+  // Persistent over output tiles: block b runs tiles b, b + gridDim.x, ... The DMA of the next tile's
+  // first K-tiles is issued BEFORE the epilogue of the current one (which stages through the 32 KiB of
+  // LDS the operand buffers leave free), so output stores and the next prologue's latency overlap.
   const int nwg = g.tiles_m * g.tiles_n;
-  const int orig = blockIdx.x;
-  const int xcd = orig & 7, q8 = nwg >> 3, rem = nwg & 7;
-  const int vt = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (orig >> 3);
-  // inside an XCD's range walk groups of kGroupM tile rows column by column: the group's A panels and
-  // the current B panel stay in that XCD's L2
-  constexpr int kGroupM = 8;
-  const int group_sz = kGroupM * g.tiles_n;
-  const int gid = vt / group_sz, in_g = vt - gid * group_sz;
-  const int first_m = gid * kGroupM;
-  const int gm = min(g.tiles_m - first_m, kGroupM);
-  const int tm = first_m + in_g % gm, tn = in_g / gm;
-  const int m0 = tm * TM, n0 = tn * TN;
   const int split = blockIdx.y;
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nt = (kend - kbeg) / TK;
-
-  // per-thread source offsets of its two DMA pieces in each of the four half-tiles (first K-tile of
-  // this split) and the per-K-tile advance of each operand
-  long long src_off[4][2];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const bool isA = w < 2;
-    const int h = w & 1;
-    const int T = isA ? A_T : B_T;
-    const long long ld = isA ? g.lda : g.ldb;
-    const int r0 = (isA ? m0 : n0) + h * 128;
-    const int rows = isA ? g.M : g.N;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int p = u * 512 + tid;
-      if (T == 0) {
-        const int row = p >> 3, cl = p & 7;
-        const int cg = cl ^ ((row >> 1) & 7);
-        int gr = r0 + row;
-        gr = gr > rows - 1 ? rows - 1 : gr;      // rows past the edge re-read the last row; never stored
-        src_off[w][u] = (long long)gr * ld + kbeg + cg * 8;
-      } else {
-        const int k = p >> 4, cl = p & 15;
-        const int cg = cl ^ swz_t256(k);
-        int col = r0 + cg * 8;
-        col = col > rows - 8 ? rows - 8 : col;   // columns past the edge re-read the last chunk
-        src_off[w][u] = (long long)(kbeg + k) * ld + col;
-      }
-    }
-  }
   const long long adv_a = A_T == 0 ? TK : (long long)TK * g.lda;
   const long long adv_b = B_T == 0 ? TK : (long long)TK * g.ldb;
   const int dma_dst = wid * 1024;          // wave-uniform; the DMA adds lane * 16
+  const int arow = wr * 64;                    // + i * 16, inside an A half-tile
+  const int brow = wc * 32;                    // + j * 16, inside a B half-tile
+
+  int m0 = 0, n0 = 0;
+  unsigned src_off[4][2];                      // element offsets; the host checks that they fit 32 bits
+  // tile index -> (m0, n0) and the per-thread source offsets of its two DMA pieces in each of the four
+  // half-tiles (first K-tile of this split)
+  auto setup_tile = [&](int it) {
+    // XCD-aware bijective map (an XCD owns a contiguous range of tiles; with gridDim.x a multiple of 8
+    // a block stays on one XCD's range for all its tiles)
+    const int xcd = it & 7, q8 = nwg >> 3, rem = nwg & 7;
+    const int vt = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (it >> 3);
+    // inside an XCD's range walk groups of kGroupM tile rows column by column: the group's A panels
+    // and the current B panel stay in that XCD's L2
+    constexpr int kGroupM = 8;
+    const int group_sz = kGroupM * g.tiles_n;
+    const int gid = vt / group_sz, in_g = vt - gid * group_sz;
+    const int first_m = gid * kGroupM;
+    const int gm = min(g.tiles_m - first_m, kGroupM);
+    m0 = (first_m + in_g % gm) * TM;
+    n0 = (in_g / gm) * TN;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const bool isA = w < 2;
+      const int h = w & 1;
+      const int T = isA ? A_T : B_T;
+      const long long ld = isA ? g.lda : g.ldb;
+      const int r0 = (isA ? m0 : n0) + h * 128;
+      const int rows = isA ? g.M : g.N;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = u * 512 + tid;
+        if (T == 0) {
+          const int row = p >> 3, cl = p & 7;
+          const int cg = cl ^ ((row >> 1) & 7);
+          int gr = r0 + row;
+          gr = gr > rows - 1 ? rows - 1 : gr;      // rows past the edge re-read the last row; never stored
+          src_off[w][u] = (unsigned)((long long)gr * ld + kbeg + cg * 8);
+        } else {
+          const int k = p >> 4, cl = p & 15;
+          const int cg = cl ^ swz_t256(k);
+          int col = r0 + cg * 8;
+          col = col > rows - 8 ? rows - 8 : col;   // columns past the edge re-read the last chunk
+          src_off[w][u] = (unsigned)((long long)(kbeg + k) * ld + col);
+        }
+      }
+    }
+  };
 
   auto issue = [&](int which, int tile) {  // which: 0 A0, 1 A1, 2 B0, 3 B1
     const unsigned short* base = which < 2 ? g.A : g.B;
     char* dst = smem + (tile & 1) * kBufBytes + which * kHalfBytes + dma_dst;
-    const long long k0 = (long long)tile * (which < 2 ? adv_a : adv_b);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + src_off[which][0] + k0), (lds_ptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + src_off[which][1] + k0), (lds_ptr_t)(dst + 8192), 16, 0, 0);
+    const unsigned k0 = (unsigned)(tile * (which < 2 ? adv_a : adv_b));
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (size_t)(src_off[which][0] + k0)), (lds_ptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (size_t)(src_off[which][1] + k0)), (lds_ptr_t)(dst + 8192), 16, 0,
+                                     0);
+  };
+  // K-tile 0 and the first two half-tiles of K-tile 1: what the main loop expects to be in flight
+  auto issue_prologue = [&]() {
+    issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0);
+    if (nt > 1) { issue(0, 1); issue(2, 1); }
   };
 
   f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue: tile 0 complete, A0 and B0 of tile 1 in flight
-  issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0);
-  if (nt > 1) {
-    issue(0, 1); issue(2, 1);
-    WAIT_VM(4);
-  } else {
-    WAIT_VM(0);
-  }
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // the two row groups run one barrier apart
-
   bf16x8_t a[4][2], b0[2][2], b1[2][2];
-  const int arow = wr * 64;                    // + i * 16, inside an A half-tile
-  const int brow = wc * 32;                    // + j * 16, inside a B half-tile
 
 #define LOAD_A(H)                                                                              \
   do {                                                                                         \
@@ -206,157 +203,165 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
     if ((TILE) < nt) { issue(WHICH, TILE); WAIT_VM(6); } else { WAIT_VM(0); }                  \
   } while (0)
 
-  for (int t = 0; t < nt; ++t) {
-    const char* buf = smem + (t & 1) * kBufBytes;
-    // phase 0: quadrant (A0, B0)
-    LOAD_B(b0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    LOAD_A(0);
-    ISSUE_OR_DRAIN(3, t + 1);
+  int it = blockIdx.x;
+  if (it < nwg) { setup_tile(it); issue_prologue(); }
+  for (; it < nwg; it += gridDim.x) {
+    const int cm0 = m0, cn0 = n0;
+    // everything outstanding (this tile's prologue, the previous tile's stores) has landed
+    WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
-    WAIT_LGKM0();
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_Q(0, 0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // phase 1: quadrant (A0, B1)
-    LOAD_B(b1, 1);
-    ISSUE_OR_DRAIN(1, t + 1);
-    __builtin_amdgcn_s_barrier();
-    WAIT_LGKM0();
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_Q(0, 1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // phase 2: quadrant (A1, B1)
-    LOAD_A(1);
-    ISSUE_OR_DRAIN(0, t + 2);
-    __builtin_amdgcn_s_barrier();
-    WAIT_LGKM0();
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_Q(1, 1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // phase 3: quadrant (A1, B0), fragments already in registers
-    ISSUE_OR_DRAIN(2, t + 2);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA_Q(1, 0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the other group's last barrier
-  WAIT_VM(0);
-  __syncthreads();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // the two row groups run one barrier apart
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (g.splits > 1) {
-    // fp32 partial slab of this split: 16 bytes per lane (4 consecutive n); reduced by dtf_splitk_reduce
-    float* W = g.W + (long long)split * g.M * g.N;
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + qi * 128 + wr * 64 + i * 16 + fr;
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int qj = 0; qj < 2; ++qj)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int n = n0 + qj * 128 + wc * 32 + j * 16 + fq * 4;
-            if (n < g.N) *reinterpret_cast<f32x4*>(W + (long long)m * g.N + n) = acc[qi * 4 + i][qj * 2 + j];
-          }
-      }
-    return;
-  }
+    for (int t = 0; t < nt; ++t) {
+      const char* buf = smem + (t & 1) * kBufBytes;
+      // phase 0: quadrant (A0, B0)
+      LOAD_B(b0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      LOAD_A(0);
+      ISSUE_OR_DRAIN(3, t + 1);
+      __builtin_amdgcn_s_barrier();
+      WAIT_LGKM0();
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA_Q(0, 0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // phase 1: quadrant (A0, B1)
+      LOAD_B(b1, 1);
+      ISSUE_OR_DRAIN(1, t + 1);
+      __builtin_amdgcn_s_barrier();
+      WAIT_LGKM0();
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA_Q(0, 1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // phase 2: quadrant (A1, B1)
+      LOAD_A(1);
+      ISSUE_OR_DRAIN(0, t + 2);
+      __builtin_amdgcn_s_barrier();
+      WAIT_LGKM0();
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA_Q(1, 1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // phase 3: quadrant (A1, B0), fragments already in registers
+      ISSUE_OR_DRAIN(2, t + 2);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA_Q(1, 0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the other group's last barrier
+    WAIT_VM(0);
+    __syncthreads();                             // every wave is done reading the operand buffers
 
-  // ---- epilogue: bias + activation in fp32, each wave stages its four 64 x 32 quadrants in its own
-  // 16 KiB of LDS and writes 64-byte row segments with 16-byte stores
-  if (g.bias || g.act) {
+    // bias is added here, with ordinary loads that are waited for before the next tile's DMA is
+    // issued: nothing in the rest of the epilogue then has to drain that DMA
+    if (g.splits == 1 && g.bias) {
 #pragma unroll
-    for (int qj = 0; qj < 2; ++qj)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + qj * 128 + wc * 32 + j * 16 + fq * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias && n < g.N) {
+      for (int c = 0; c < 4; ++c) {
+        const int n = cn0 + (c >> 1) * 128 + wc * 32 + (c & 1) * 16 + fq * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (n < g.N) {
           if (g.bias_dtype == 0) {
-            const f32x4 tb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.bias) + n);
-            bv[0] = tb[0]; bv[1] = tb[1]; bv[2] = tb[2]; bv[3] = tb[3];
+            bv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.bias) + n);
           } else {
             const u16x4 tb = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(g.bias) + n);
             bv[0] = bf16_to_f32(tb[0]); bv[1] = bf16_to_f32(tb[1]); bv[2] = bf16_to_f32(tb[2]); bv[3] = bf16_to_f32(tb[3]);
           }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) acc[i][c] += bv;
+      }
+    }
+    WAIT_VM(0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int next = it + gridDim.x;
+    if (next < nwg) { setup_tile(next); issue_prologue(); }
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (g.splits > 1) {
+      // fp32 partial slab of this split: 16 bytes per lane (4 consecutive n); reduced by dtf_splitk_reduce
+      float* W = g.W + (long long)split * g.M * g.N;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = acc[i][qj * 2 + j][r] + bv[r];
-            if (g.act == 1) v = fmaxf(v, 0.f);
-            else if (g.act == 2) v = gelu_erf256(v);
-            acc[i][qj * 2 + j][r] = v;
+      for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = cm0 + qi * 128 + wr * 64 + i * 16 + fr;
+          if (m >= g.M) continue;
+#pragma unroll
+          for (int qj = 0; qj < 2; ++qj)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int n = cn0 + qj * 128 + wc * 32 + j * 16 + fq * 4;
+              if (n < g.N) *reinterpret_cast<f32x4*>(W + (long long)m * g.N + n) = acc[qi * 4 + i][qj * 2 + j];
+            }
+        }
+      continue;
+    }
+
+    // ---- epilogue: bias + activation in fp32; a wave stages one 64 x 32 quadrant at a time in its 4 KiB
+    // of the spare LDS and writes 64-byte row segments with 16-byte stores
+    char* blk = smem + kLds256 + wid * 4096;
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+      for (int qj = 0; qj < 2; ++qj) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            f32x4 v = acc[qi * 4 + i][qj * 2 + j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = v[r];
+              if (g.act == 1) x = fmaxf(x, 0.f);
+              else if (g.act == 2) x = gelu_erf256(x);
+              v[r] = x;
+            }
+            u32x2 o;
+            o[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            o[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<u32x2*>(blk + (i * 16 + fr) * 64 + j * 32 + fq * 8) = o;
           }
+        // the staging block is private to the wave: LDS operations of one wave execute in order
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int idx = v * 64 + lane;
+          const int row = idx >> 2, c16 = idx & 3;
+          const int m = cm0 + qi * 128 + wr * 64 + row;
+          const int n = cn0 + qj * 128 + wc * 32 + c16 * 8;
+          u32x4 val = *reinterpret_cast<const u32x4*>(blk + row * 64 + c16 * 16);
+          if (m < g.M && n < g.N) {
+            if (g.Cin) {
+              // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
+              const u32x4 ci = *reinterpret_cast<const u32x4*>(g.Cin + (long long)m * g.ldc + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(ci[e] << 16);
+                const float hi = __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(ci[e] & 0xffff0000u);
+                val[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+              }
+            }
+            *reinterpret_cast<u32x4*>(g.C + (long long)m * g.ldc + n) = val;
+          }
+        }
       }
   }
-  char* stage = smem + wid * 16384;
-#pragma unroll
-  for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-    for (int qj = 0; qj < 2; ++qj) {
-      char* blk = stage + (qi * 2 + qj) * 4096;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const f32x4 v = acc[qi * 4 + i][qj * 2 + j];
-          u32x2 o;
-          o[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-          o[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-          *reinterpret_cast<u32x2*>(blk + (i * 16 + fr) * 64 + j * 32 + fq * 8) = o;
-        }
-    }
-  // the staging region is private to the wave: its own LDS accesses are ordered by the waits the
-  // compiler places for them. The accumulate input is fetched for a whole quadrant before it is used,
-  // so that its 4 loads per lane are in flight together (one block per CU: nothing else hides them).
-#pragma unroll
-  for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-    for (int qj = 0; qj < 2; ++qj) {
-      const char* blk = stage + (qi * 2 + qj) * 4096;
-      u32x4 ci[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int idx = v * 64 + lane;
-        const int row = idx >> 2, c16 = idx & 3;
-        const int m = m0 + qi * 128 + wr * 64 + row;
-        const int n = n0 + qj * 128 + wc * 32 + c16 * 8;
-        ci[v] = u32x4{0u, 0u, 0u, 0u};
-        if (g.Cin && m < g.M && n < g.N) ci[v] = *reinterpret_cast<const u32x4*>(g.Cin + (long long)m * g.ldc + n);
-      }
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int idx = v * 64 + lane;
-        const int row = idx >> 2, c16 = idx & 3;
-        const int m = m0 + qi * 128 + wr * 64 + row;
-        const int n = n0 + qj * 128 + wc * 32 + c16 * 8;
-        u32x4 val = *reinterpret_cast<const u32x4*>(blk + row * 64 + c16 * 16);
-        if (m < g.M && n < g.N) {
-          if (g.Cin) {
-            // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(ci[v][e] << 16);
-              const float hi = __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(ci[v][e] & 0xffff0000u);
-              val[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
-            }
-          }
-          *reinterpret_cast<u32x4*>(g.C + (long long)m * g.ldc + n) = val;
-        }
-      }
-    }
 }
 
 }  // namespace
+
+static int g_persist256 = 0;   // measured neutral for NT/NN and worse with split-K: the output burst, not the prologue, bounds short-K shapes
+constexpr int kCus256 = 256;
+
+// 1: persistent grid (one workgroup per CU walks several tiles), 0: one workgroup per tile (measurement hook)
+DTF_API void dtf_gemm256_set_persistent(int on) { g_persist256 = on; }
 
 // defined in gemm.hip: sums fp32 slabs [splits][M][N] into C with bias / activation
 extern "C" int dtf_splitk_reduce(const float* W, void* C, const void* bias, int bias_dtype, int act, int out_fp32,
@@ -373,6 +378,10 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (K % TK || N % 8 || lda % 8 || ldb % 8 || ldc % 8 || M < 8 || N < 8) return -9;
   if (layout == 2 && M % 8) return -9;
+  // operand element offsets are kept in 32 bits inside the kernel
+  const long long a_elems = layout == 2 ? (long long)K * lda : (long long)M * lda;
+  const long long b_elems = layout == 0 ? (long long)N * ldb : (long long)K * ldb;
+  if (a_elems >= (1LL << 32) || b_elems >= (1LL << 32)) return -9;
   if (layout < 0 || layout > 2) return -1;
   static bool attr_set = false;
   if (!attr_set) {
@@ -380,7 +389,7 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
                           reinterpret_cast<const void*>(gemm256_kernel<0, 1>),
                           reinterpret_cast<const void*>(gemm256_kernel<1, 1>)};
     for (const void* f : fns) {
-      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLds256);
+      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsAll);
       if (e != hipSuccess) return (int)e;
     }
     attr_set = true;
@@ -394,11 +403,15 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias_dtype = bias_dtype; g.act = act;
   g.tiles_m = (M + TM - 1) / TM; g.tiles_n = (N + TN - 1) / TN;
   g.W = (float*)workspace; g.k_per_split = kps; g.splits = splits; g.Cin = (const unsigned short*)cin;
-  const dim3 grid(g.tiles_m * g.tiles_n, splits);
+  // persistent: one workgroup per CU (the kernel takes the whole LDS), each walking its share of tiles
+  const int nwg = g.tiles_m * g.tiles_n;
+  int gx = g_persist256 ? (kCus256 / splits > 8 ? kCus256 / splits / 8 * 8 : 8) : nwg;
+  if (gx > nwg) gx = nwg;
+  const dim3 grid(gx, splits);
   switch (layout) {
-    case 0: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid, dim3(kT256), kLds256, stream, g); break;
-    case 1: hipLaunchKernelGGL((gemm256_kernel<0, 1>), grid, dim3(kT256), kLds256, stream, g); break;
-    default: hipLaunchKernelGGL((gemm256_kernel<1, 1>), grid, dim3(kT256), kLds256, stream, g); break;
+    case 0: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid, dim3(kT256), kLdsAll, stream, g); break;
+    case 1: hipLaunchKernelGGL((gemm256_kernel<0, 1>), grid, dim3(kT256), kLdsAll, stream, g); break;
+    default: hipLaunchKernelGGL((gemm256_kernel<1, 1>), grid, dim3(kT256), kLdsAll, stream, g); break;
   }
   if (splits > 1) return dtf_splitk_reduce((const float*)workspace, C, bias, bias_dtype, act, 0, splits, M, N, ldc, stream);
   return (int)hipGetLastError();
