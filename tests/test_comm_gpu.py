@@ -144,3 +144,82 @@ def test_peer_group_processes_sharing_one_gpu(world):
                 assert v, (r, k)
             else:
                 assert v < 1e-5, (r, k, v)
+
+
+# ------------------------------------- whole strategy on peer-pointer all-reduce, ranks share the GPU
+def _ipc_strategy_worker(rank, world, port, q):
+    try:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        from distributed_tensorflow_amd.comm.backend import Comm
+        from distributed_tensorflow_amd.engine.optimizer import Adam
+        from distributed_tensorflow_amd.engine.replica import TrainConfig
+        from distributed_tensorflow_amd.models.mlp import reference_mlp
+        from distributed_tensorflow_amd.parallel.mirrored import CustomAllReduceStrategy
+
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        comm = Comm.init(rank, world, dev, master_port=port, timeout_s=60, backend="gloo")
+        torch.manual_seed(0)
+        st = CustomAllReduceStrategy(reference_mlp(dropout=0.0), comm, TrainConfig(loss_reduction="mean", seed=0),
+                                     optimizer=Adam(1e-3), algorithm="ipc-direct")
+        g = torch.Generator().manual_seed(7)
+        xs = torch.rand(6, 32 * world, 28, 28, 1, generator=g)
+        ys = torch.randint(0, 10, (6, 32 * world), generator=g)
+        for i in range(6):
+            x = xs[i, rank * 32:(rank + 1) * 32].to(dev)
+            y = ys[i, rank * 32:(rank + 1) * 32].to(dev)
+            st.train_step(x, y)
+        torch.cuda.synchronize()
+        st._peers.check()
+        used = sorted(set(st.used_algorithms))
+        import numpy as np
+        w = np.concatenate([a.reshape(-1) for a in st.replica.model.get_weights()])
+        q.put((rank, {"w": w, "used": used}))
+        st._peers.close()
+        comm.shutdown()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, {"error": f"{e}\n{traceback.format_exc()}"}))
+
+
+def test_custom_strategy_on_peer_pointer_allreduce_matches_single_process():
+    """Two ranks that share the GPU train with the hand-written IPC all-reduce; the result equals one
+    process training on the concatenated batch (mean loss, so the averaged gradients coincide)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ipc_strategy_worker, args=(r, world, 29671, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r, res = q.get(timeout=110)
+            got[r] = res
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+    for r, res in got.items():
+        assert "error" not in res, res.get("error")
+    import numpy as np
+    assert np.array_equal(got[0]["w"], got[1]["w"])          # replicas stay bit-identical
+    assert all(u.startswith("ipc-") for u in got[0]["used"])
+
+    from distributed_tensorflow_amd.comm.backend import Comm
+    from distributed_tensorflow_amd.engine.optimizer import Adam
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    from distributed_tensorflow_amd.parallel.mirrored import MirroredStrategy
+    dev = _dev()
+    torch.manual_seed(0)
+    ref = MirroredStrategy(reference_mlp(dropout=0.0), Comm(0, 1, dev), TrainConfig(loss_reduction="mean", seed=0),
+                           optimizer=Adam(1e-3))
+    g = torch.Generator().manual_seed(7)
+    xs = torch.rand(6, 32 * world, 28, 28, 1, generator=g)
+    ys = torch.randint(0, 10, (6, 32 * world), generator=g)
+    for i in range(6):
+        ref.train_step(xs[i].to(dev), ys[i].to(dev))
+    w_ref = np.concatenate([a.reshape(-1) for a in ref.replica.model.get_weights()])
+    assert np.allclose(got[0]["w"], w_ref, atol=2e-5, rtol=1e-4), float(np.abs(got[0]["w"] - w_ref).max())
