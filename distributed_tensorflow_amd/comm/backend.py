@@ -22,10 +22,15 @@ import torch.distributed as dist
 
 
 class Comm:
-    def __init__(self, rank: int = 0, world: int = 1, device: torch.device | str = "cpu", group=None):
+    def __init__(self, rank: int = 0, world: int = 1, device: torch.device | str = "cpu", group=None,
+                 backend: str | None = None):
         self.rank, self.world = rank, world
         self.device = torch.device(device)
         self.group = group
+        self.backend = backend or ("nccl" if self.device.type == "cuda" else "gloo")
+        # gloo lacks reduce_scatter / all_to_all: those collectives are composed from the ones it has
+        # (also when gloo carries GPU tensors, e.g. several test ranks sharing one device)
+        self.composed = self.backend == "gloo"
 
     # ------------------------------------------------------------------ setup
     @classmethod
@@ -46,7 +51,7 @@ class Comm:
                 kw["device_id"] = device
             dist.init_process_group(backend, init_method=f"tcp://{master_addr}:{master_port}", rank=rank,
                                     world_size=world, timeout=datetime.timedelta(seconds=timeout_s), **kw)
-        return cls(rank, world, device)
+        return cls(rank, world, device, backend=backend)
 
     @classmethod
     def from_env(cls, device: torch.device | str, timeout_s: float = 300.0) -> "Comm":
@@ -60,7 +65,7 @@ class Comm:
         """A communicator over ``ranks`` (collective call on the parent group)."""
         g = dist.new_group(list(ranks))
         r = list(ranks).index(self.rank) if self.rank in ranks else -1
-        c = Comm(r, len(ranks), self.device, g)
+        c = Comm(r, len(ranks), self.device, g, backend=self.backend)
         c._global_ranks = list(ranks)
         return c
 
@@ -85,7 +90,7 @@ class Comm:
             if out.data_ptr() != inp.data_ptr():
                 out.copy_(inp)
             return None
-        if self.device.type == "cpu":
+        if self.composed:
             # gloo has no reduce_scatter: reduce the whole buffer, keep the local slice
             w = dist.all_reduce(inp, group=self.group, async_op=False)
             n = out.numel()
@@ -99,7 +104,7 @@ class Comm:
             if out.data_ptr() != inp.data_ptr():
                 out.copy_(inp)
             return None
-        if self.device.type == "cpu":
+        if self.composed:
             n = inp.numel()
             chunks = [out[i * n:(i + 1) * n] for i in range(self.world)]
             src = inp.clone() if inp.data_ptr() == chunks[self.rank].data_ptr() else inp
@@ -110,7 +115,7 @@ class Comm:
         if self.world == 1:
             out.copy_(inp)
             return None
-        if self.device.type == "cpu":
+        if self.composed:
             n = inp.numel() // self.world
             ops = []
             for r in range(self.world):
@@ -136,7 +141,7 @@ class Comm:
 
     def barrier(self) -> None:
         if self.world > 1:
-            if self.device.type == "cuda":
+            if self.device.type == "cuda" and not self.composed:
                 dist.barrier(group=self.group, device_ids=[self.device.index or 0])
             else:
                 dist.barrier(group=self.group)

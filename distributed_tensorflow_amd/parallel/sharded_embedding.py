@@ -33,7 +33,7 @@ def _all_to_all_v(comm: Comm, send: torch.Tensor, send_counts: list[int], recv_c
     if comm.world == 1:
         out.copy_(send)
         return out
-    if comm.device.type == "cuda":
+    if not getattr(comm, "composed", comm.device.type != "cuda"):
         dist.all_to_all_single(out, send.contiguous(), recv_counts, send_counts, group=comm.group)
         return out
     so = ro = 0

@@ -223,3 +223,92 @@ def test_custom_strategy_on_peer_pointer_allreduce_matches_single_process():
         ref.train_step(xs[i].to(dev), ys[i].to(dev))
     w_ref = np.concatenate([a.reshape(-1) for a in ref.replica.model.get_weights()])
     assert np.allclose(got[0]["w"], w_ref, atol=2e-5, rtol=1e-4), float(np.abs(got[0]["w"] - w_ref).max())
+
+
+# --------------------- every collective strategy with two ranks that share the GPU (gloo carries GPU tensors)
+def _strategy_worker(rank, world, port, kind, q):
+    try:
+        from distributed_tensorflow_amd.comm.backend import Comm
+        from distributed_tensorflow_amd.engine.optimizer import Adam
+        from distributed_tensorflow_amd.engine.replica import TrainConfig
+        from distributed_tensorflow_amd.models.mlp import reference_mlp
+        from distributed_tensorflow_amd.parallel import mirrored, ps
+
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        comm = Comm.init(rank, world, dev, master_port=port, timeout_s=60, backend="gloo")
+        torch.manual_seed(0)
+        cfg = TrainConfig(loss_reduction="mean", seed=0, bucket_bytes=256 << 10, first_bucket_bytes=64 << 10)
+        model = reference_mlp(dropout=0.0)
+        if kind == "keras":
+            st = mirrored.MirroredStrategy(model, comm, cfg, optimizer=Adam(1e-3))
+        elif kind == "custom-ring":
+            st = mirrored.CustomAllReduceStrategy(model, comm, cfg, optimizer=Adam(1e-3), algorithm="ring")
+        elif kind == "sync":
+            st = ps.SyncPSStrategy(model, comm, cfg, optimizer=Adam(1e-3))
+        elif kind == "async":
+            st = ps.AsyncPSStrategy(model, comm, cfg, optimizer=Adam(1e-3))
+        else:
+            st = mirrored.GraphStrategy(model, comm, cfg, optimizer=Adam(1e-3), degree=1)
+        g = torch.Generator().manual_seed(7)
+        xs = torch.rand(6, 32 * world, 28, 28, 1, generator=g)
+        ys = torch.randint(0, 10, (6, 32 * world), generator=g)
+        losses = []
+        for i in range(6):
+            x = xs[i, rank * 32:(rank + 1) * 32].to(dev)
+            y = ys[i, rank * 32:(rank + 1) * 32].to(dev)
+            losses.append(float(st.train_step(x, y)))
+        st.finalize()
+        torch.cuda.synchronize()
+        import numpy as np
+        w = np.concatenate([a.reshape(-1) for a in st.replica.model.get_weights()])
+        q.put((rank, {"w": w, "losses": losses}))
+        comm.barrier()
+        comm.shutdown()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, {"error": f"{e}\n{traceback.format_exc()}"}))
+
+
+@pytest.mark.parametrize("kind", ["keras", "custom-ring", "sync", "async", "graph"])
+def test_collective_strategies_two_ranks_on_one_gpu(kind):
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29680 + ["keras", "custom-ring", "sync", "async", "graph"].index(kind)
+    procs = [ctx.Process(target=_strategy_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r, res = q.get(timeout=110)
+            got[r] = res
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+    for r, res in got.items():
+        assert "error" not in res, res.get("error")
+    assert np.allclose(got[0]["w"], got[1]["w"], atol=1e-6)          # replicas agree after finalize()
+    assert all(np.isfinite(got[r]["losses"]).all() for r in got)
+    if kind in ("keras", "custom-ring", "sync"):
+        # synchronous strategies reproduce single-process training on the concatenated batch
+        from distributed_tensorflow_amd.comm.backend import Comm
+        from distributed_tensorflow_amd.engine.optimizer import Adam
+        from distributed_tensorflow_amd.engine.replica import TrainConfig
+        from distributed_tensorflow_amd.models.mlp import reference_mlp
+        from distributed_tensorflow_amd.parallel.mirrored import MirroredStrategy
+        dev = _dev()
+        torch.manual_seed(0)
+        ref = MirroredStrategy(reference_mlp(dropout=0.0), Comm(0, 1, dev), TrainConfig(loss_reduction="mean", seed=0),
+                               optimizer=Adam(1e-3))
+        g = torch.Generator().manual_seed(7)
+        xs = torch.rand(6, 32 * world, 28, 28, 1, generator=g)
+        ys = torch.randint(0, 10, (6, 32 * world), generator=g)
+        for i in range(6):
+            ref.train_step(xs[i].to(dev), ys[i].to(dev))
+        w_ref = np.concatenate([a.reshape(-1) for a in ref.replica.model.get_weights()])
+        assert np.allclose(got[0]["w"], w_ref, atol=3e-5, rtol=1e-4), float(np.abs(got[0]["w"] - w_ref).max())
