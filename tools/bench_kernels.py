@@ -115,6 +115,26 @@ def main():
         print(f"gemm {M}x{N}x{Kd}: " + " ".join(f"{k}={v:.1f}" for k, v in r.items() if k.endswith("TF")), flush=True)
         del A, Bm, Bt, G
 
+    # ---- fused attention (BERT-base shape) against the unfused GEMM + softmax path
+    from distributed_tensorflow_amd.ops import attention as ATT
+    Bq, Sq, nh, hd = 64, 512, 12, 64
+    qkv = (torch.randn(Bq, Sq, 3, nh, hd, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    do = torch.randn(Bq, Sq, nh, hd, device=DEV).to(torch.bfloat16)
+    fl_f = 4.0 * Bq * nh * Sq * Sq * hd
+    for name, on in (("flash", True), ("unfused", False)):
+        ATT.set_flash(on)
+        with torch.no_grad():
+            tf_ = timeit(lambda: ATT.self_attention(qkv), iters=10, warmup=3)
+
+        def fb():
+            qkv.grad = None
+            ATT.self_attention(qkv).backward(do)
+        tt = timeit(fb, iters=10, warmup=3)
+        res[f"attention_{name}_b64_s512_h12"] = {"fwd_ms": tf_ * 1e3, "fwd_TF": fl_f / tf_ / 1e12, "fwd_bwd_ms": tt * 1e3,
+                                                 "fwd_bwd_TF_useful": 3.5 * fl_f / tt / 1e12}
+    ATT.set_flash(True)
+    del qkv, do
+
     # ---- peer-pointer collective kernels on one device (virtual ranks: "peers" are local buffers),
     #      bytes = what one rank's kernels read + write for a full all-reduce
     from distributed_tensorflow_amd.comm.ipc import LocalPeers

@@ -40,6 +40,11 @@ def main():
         rep(lambda: gemm.gemm_nn(G, W))
         rep(lambda: gemm.gemm_tn(G, A))
         del A, W, G
+    # fused attention, BERT-base shape (64 x 512 tokens, 12 heads of 64)
+    from distributed_tensorflow_amd.ops import attention as A
+    qkv = (torch.randn(64, 512, 3, 12, 64, device=DEV) * 0.5).to(bf).requires_grad_(True)
+    rep(lambda: A.self_attention(qkv).sum().backward())
+    del qkv
     # implicit-GEMM 3x3 convolution, fwd + bwd
     C.set_convkxk_backend("gemm")
     x = torch.randn(256, 128, 28, 28, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
