@@ -30,7 +30,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DTF_BENCH_BATCH", "256")), help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DTF_BENCH_BATCH", "512")), help="per-GPU batch")
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--bucket-mb", type=int, default=16)
     ap.add_argument("--conv1x1", default=None, choices=[None, "auto", "gemm", "library"])
