@@ -26,6 +26,7 @@
 // hardware-transposing ds_read_b64_tr_b16; the DMA source permutation is the XOR of that layout.
 // The reference trains its dense layers through TensorFlow's CPU MatMul (reference initializer.py:16-18).
 #include "dtf_common.h"
+#include <type_traits>
 
 using namespace dtf;
 
@@ -57,6 +58,7 @@ struct G256Args {
   float* W;              // fp32 slabs [splits][M][N] when splits > 1
   int k_per_split;       // multiple of TK
   int splits;
+  long long* stamps;     // diagnostic: per workgroup 4 wall-clock stamps of its first tile (null = off)
 };
 
 __device__ __forceinline__ int swz256(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -204,6 +206,8 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
   } while (0)
 
   int it = blockIdx.x;
+  const bool stamp = g.stamps != nullptr && tid == 0;
+  if (stamp) g.stamps[blockIdx.x * 4 + 0] = wall_clock64();
   if (it < nwg) { setup_tile(it); issue_prologue(); }
   for (; it < nwg; it += gridDim.x) {
     const int cm0 = m0, cn0 = n0;
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
     WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // the two row groups run one barrier apart
+    if (stamp && it == (int)blockIdx.x) g.stamps[blockIdx.x * 4 + 1] = wall_clock64();
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -258,6 +263,7 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
     if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the other group's last barrier
     WAIT_VM(0);
     __syncthreads();                             // every wave is done reading the operand buffers
+    if (stamp && it == (int)blockIdx.x) g.stamps[blockIdx.x * 4 + 2] = wall_clock64();
 
     // bias is added here, with ordinary loads that are waited for before the next tile's DMA is
     // issued: nothing in the rest of the epilogue then has to drain that DMA
@@ -305,58 +311,74 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
       continue;
     }
 
-    // ---- epilogue: bias + activation in fp32; a wave stages one 64 x 32 quadrant at a time in its 4 KiB
-    // of the spare LDS and writes 64-byte row segments with 16-byte stores
+    // ---- epilogue: activation in fp32; a wave stages one 64 x 32 quadrant at a time in its 4 KiB of the
+    // spare LDS and writes 64-byte row segments with 16-byte stores. The activation and the accumulate
+    // input are compile-time choices of the body: tested per element they cost a branch (and the
+    // instruction fetch of the skipped code) 128 times per lane.
     char* blk = smem + kLds256 + wid * 4096;
+    auto epilogue = [&](auto act_c, auto cin_c) {
+      constexpr int ACT = decltype(act_c)::value;
+      constexpr bool CIN = decltype(cin_c)::value;
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
+      for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-      for (int qj = 0; qj < 2; ++qj) {
+        for (int qj = 0; qj < 2; ++qj) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            f32x4 v = acc[qi * 4 + i][qj * 2 + j];
+            for (int j = 0; j < 2; ++j) {
+              f32x4 v = acc[qi * 4 + i][qj * 2 + j];
+              if (ACT != 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float x = v[r];
-              if (g.act == 1) x = fmaxf(x, 0.f);
-              else if (g.act == 2) x = gelu_erf256(x);
-              v[r] = x;
-            }
-            u32x2 o;
-            o[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            o[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-            *reinterpret_cast<u32x2*>(blk + (i * 16 + fr) * 64 + j * 32 + fq * 8) = o;
-          }
-        // the staging block is private to the wave: LDS operations of one wave execute in order
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int idx = v * 64 + lane;
-          const int row = idx >> 2, c16 = idx & 3;
-          const int m = cm0 + qi * 128 + wr * 64 + row;
-          const int n = cn0 + qj * 128 + wc * 32 + c16 * 8;
-          u32x4 val = *reinterpret_cast<const u32x4*>(blk + row * 64 + c16 * 16);
-          if (m < g.M && n < g.N) {
-            if (g.Cin) {
-              // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
-              const u32x4 ci = *reinterpret_cast<const u32x4*>(g.Cin + (long long)m * g.ldc + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(ci[e] << 16);
-                const float hi = __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(ci[e] & 0xffff0000u);
-                val[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                for (int r = 0; r < 4; ++r) v[r] = ACT == 1 ? fmaxf(v[r], 0.f) : gelu_erf256(v[r]);
               }
+              u32x2 o;
+              o[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+              o[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+              *reinterpret_cast<u32x2*>(blk + (i * 16 + fr) * 64 + j * 32 + fq * 8) = o;
             }
-            *reinterpret_cast<u32x4*>(g.C + (long long)m * g.ldc + n) = val;
+          // the staging block is private to the wave: LDS operations of one wave execute in order
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int idx = v * 64 + lane;
+            const int row = idx >> 2, c16 = idx & 3;
+            const int m = cm0 + qi * 128 + wr * 64 + row;
+            const int n = cn0 + qj * 128 + wc * 32 + c16 * 8;
+            u32x4 val = *reinterpret_cast<const u32x4*>(blk + row * 64 + c16 * 16);
+            if (m < g.M && n < g.N) {
+              if (CIN) {
+                // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
+                const u32x4 ci = *reinterpret_cast<const u32x4*>(g.Cin + (long long)m * g.ldc + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(ci[e] << 16);
+                  const float hi = __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(ci[e] & 0xffff0000u);
+                  val[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                }
+              }
+              *reinterpret_cast<u32x4*>(g.C + (long long)m * g.ldc + n) = val;
+            }
           }
         }
-      }
+    };
+    using std::integral_constant;
+    if (g.Cin) epilogue(integral_constant<int, 0>{}, integral_constant<bool, true>{});
+    else if (g.act == 0) epilogue(integral_constant<int, 0>{}, integral_constant<bool, false>{});
+    else if (g.act == 1) epilogue(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+    else epilogue(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+    if (stamp && it == (int)blockIdx.x) {
+      g.stamps[blockIdx.x * 4 + 2] = wall_clock64() - g.stamps[blockIdx.x * 4 + 2];   // issue time of the epilogue
+      WAIT_VM(0);
+      g.stamps[blockIdx.x * 4 + 3] = wall_clock64();
+    }
   }
 }
 
 }  // namespace
 
+static long long* g_stamps256 = nullptr;
+// diagnostic: device buffer of 4 * gridDim.x 64-bit stamps filled by the next launches (null = off)
+DTF_API void dtf_gemm256_set_stamps(void* p) { g_stamps256 = (long long*)p; }
 static int g_persist256 = 0;   // measured neutral for NT/NN and worse with split-K: the output burst, not the prologue, bounds short-K shapes
 constexpr int kCus256 = 256;
 
@@ -395,6 +417,7 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
     attr_set = true;
   }
   if (splits < 1 || cin) splits = 1;               // slabs do not carry the accumulate input
+  if (cin && act != 0) return -9;                  // the accumulate epilogue has no activation
   int kps = ((K + splits - 1) / splits + TK - 1) / TK * TK;
   splits = (K + kps - 1) / kps;
   if (splits > 1 && !workspace) return -3;
@@ -403,6 +426,7 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias_dtype = bias_dtype; g.act = act;
   g.tiles_m = (M + TM - 1) / TM; g.tiles_n = (N + TN - 1) / TN;
   g.W = (float*)workspace; g.k_per_split = kps; g.splits = splits; g.Cin = (const unsigned short*)cin;
+  g.stamps = g_stamps256;
   // persistent: one workgroup per CU (the kernel takes the whole LDS), each walking its share of tiles
   const int nwg = g.tiles_m * g.tiles_n;
   int gx = g_persist256 ? (kCus256 / splits > 8 ? kCus256 / splits / 8 * 8 : 8) : nwg;
