@@ -410,7 +410,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
       t = tnext;
     }
   } else {
-    // one LDS buffer (32 KiB, up to 5 blocks per CU): the next tile waits in registers while this one
+    // one LDS buffer (32 KiB: residency is then set by the ~156 registers per lane, 3 blocks per CU instead of the 2 that 64 KiB allow): the next tile waits in registers while this one
     // is read. For short-K, bandwidth-bound shapes the extra resident blocks hide more latency than
     // the second buffer does.
     if (t < nt) {
