@@ -85,6 +85,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--graph", action="store_true",
                    help="capture the train step into a hipGraph (GPU; keras and collective sync strategies)")
+    p.add_argument("--verify-replicas", type=int, default=0, metavar="N",
+                   help="debug: every N steps compare the master-weight checksum across ranks (synchronous strategies)")
     p.add_argument("--fault-inject", default=None, help="RANK:STEP -- kill that worker at that step (testing)")
     return p
 
@@ -127,7 +129,8 @@ def _train_config(args, centralized: bool, shard_ways: int = 1):
     from ..engine.replica import TrainConfig
     red = args.loss_reduction or ("sum" if centralized else "mean")
     return TrainConfig(loss_reduction=red, param_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
-                       shard_ways=shard_ways, seed=args.seed, graph=bool(getattr(args, "graph", False)))
+                       shard_ways=shard_ways, seed=args.seed, graph=bool(getattr(args, "graph", False)),
+                       verify_replicas=int(getattr(args, "verify_replicas", 0) or 0))
 
 
 # ----------------------------------------------------------------------------- rank bodies

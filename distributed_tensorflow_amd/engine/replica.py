@@ -40,6 +40,7 @@ class TrainConfig:
     shard_ways: int = 1
     seed: int = 0
     graph: bool = False                   # capture the whole train step into a hipGraph (GPU, static shapes)
+    verify_replicas: int = 0              # debug: compare the master-weight checksum across ranks every N steps
     extra: dict = field(default_factory=dict)
 
 

@@ -24,8 +24,13 @@ from ..engine.replica import Replica, TrainConfig
 from ..obs.metrics import MetricsLogger
 
 
+class ReplicaDivergence(RuntimeError):
+    """The replicas of a strategy that keeps them bit-identical no longer agree."""
+
+
 class Strategy:
     name = "base"
+    replicas_agree = False      # every rank holds the same master weights after each step
     graph_capturable = False    # train_step is stream-ordered end to end (no host round trip inside)
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None,
@@ -78,6 +83,23 @@ class Strategy:
             for m in self.sparse_modules:
                 m.apply(scale)
 
+    def check_replicas(self, step: int = -1) -> None:
+        """Debug check of the synchronous strategies: the fp64 (sum, sum of squares) of the master
+        weights must be identical on every rank -- the all-reduce / parameter-server apply is
+        deterministic and identical across replicas, so any difference is a lost or doubled
+        update. Costs one 4-number all-reduce; raises :class:`ReplicaDivergence` on every rank."""
+        if not self.replicas_agree or self.comm.world == 1:
+            return
+        c = self.flat.checksum()                       # fp64, on the arena's device
+        t = torch.cat([c, -c])
+        self.comm.all_reduce(t, op=dist.ReduceOp.MAX)  # max and (negated) min in one collective
+        t, c = t.cpu(), c.cpu()
+        hi, lo = t[:2], -t[2:]
+        if not torch.equal(hi, lo):
+            raise ReplicaDivergence(
+                f"step {step}: master weights differ across ranks (checksum max {hi.tolist()} != min {lo.tolist()}; "
+                f"this rank {c.tolist()})")
+
     def finalize(self) -> None:
         """Brings every replica to the final model (no-op for strategies whose replicas agree)."""
 
@@ -119,6 +141,8 @@ class Strategy:
                     self.metrics.log(step=it_count, epoch=ep, loss=float(last_loss), step_s=time.time() - ts,
                                      examples=int(y.shape[0]))
                 it_count += 1
+                if self.cfg.verify_replicas and it_count % self.cfg.verify_replicas == 0:
+                    self.check_replicas(it_count)
         self.finalize()
         self.sync_device()
         self.comm.barrier()

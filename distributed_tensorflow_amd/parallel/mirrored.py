@@ -34,6 +34,7 @@ from .base import Strategy
 
 class MirroredStrategy(Strategy):
     name = "keras"
+    replicas_agree = True
     graph_capturable = True
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None, metrics=None):
@@ -60,6 +61,7 @@ class MirroredStrategy(Strategy):
 
 class CustomAllReduceStrategy(Strategy):
     name = "custom"
+    replicas_agree = True
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None, metrics=None,
                  algorithm: str = "auto"):

@@ -43,6 +43,7 @@ from .base import Strategy
 class SyncPSStrategy(Strategy):
     graph_capturable = True
     name = "sync"
+    replicas_agree = True
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None, metrics=None,
                  apply: str = "reduced", optimizer_state: str | None = None):

@@ -269,3 +269,35 @@ def test_async_ps_applies_every_gradient_and_replicas_end_equal(placement, world
     for _, _, version, _, max_stale in servers:
         assert version == n_workers * steps                      # one apply per (worker, step)
         assert max_stale <= n_workers * 2
+
+
+# ------------------------------------------------------------------ replica-consistency debug mode
+def _verify_body(comm, kind, corrupt):
+    from distributed_tensorflow_amd.engine.optimizer import Adam
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    from distributed_tensorflow_amd.parallel import mirrored, ps
+    from distributed_tensorflow_amd.parallel.base import ReplicaDivergence
+    torch.manual_seed(0)
+    cfg = TrainConfig(loss_reduction="mean", verify_replicas=1)
+    model = reference_mlp(dropout=0.0)
+    st = (mirrored.MirroredStrategy(model, comm, cfg, optimizer=Adam()) if kind == "keras"
+          else ps.SyncPSStrategy(model, comm, cfg, optimizer=Adam(), apply="reduced"))
+    st.broadcast_initial()
+    x, y, _, _ = _make_data(comm.world, comm.rank)
+    st.train_step(x, y)
+    st.check_replicas(1)                     # agreeing replicas pass
+    if corrupt and comm.rank == 1:
+        st.flat.master[3] += 1e-3            # a lost / doubled update on one rank
+    try:
+        st.check_replicas(2)
+    except ReplicaDivergence as e:
+        return "diverged: " + str(e)[:40]
+    return "ok"
+
+
+@pytest.mark.parametrize("kind", ["keras", "sync"])
+def test_verify_replicas_detects_a_diverged_rank_on_every_rank(kind):
+    assert _run(_verify_body, 2, kind, False) == ["ok", "ok"]
+    out = _run(_verify_body, 2, kind, True)
+    assert all(o.startswith("diverged") for o in out), out
