@@ -74,23 +74,57 @@ __device__ __forceinline__ bf16x8_t frag_tr(const char* img, int c0, int ks, int
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// two floats -> packed bf16 pair in one v_cvt_pk_bf16_f32 (round to nearest even)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// the bare v_exp_f32: arguments here are <= 0 (or far below), where the denormal fix-up of exp2f() buys nothing
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // two accumulator blocks (16-key blocks 2s and 2s+1 of one query column) -> the bf16 operand of the next product
 __device__ __forceinline__ bf16x8_t pack_p(const f32x4& a, const f32x4& b) {
   u32x4 r;
-  r[0] = (unsigned)f32_to_bf16(a[0]) | ((unsigned)f32_to_bf16(a[1]) << 16);
-  r[1] = (unsigned)f32_to_bf16(a[2]) | ((unsigned)f32_to_bf16(a[3]) << 16);
-  r[2] = (unsigned)f32_to_bf16(b[0]) | ((unsigned)f32_to_bf16(b[1]) << 16);
-  r[3] = (unsigned)f32_to_bf16(b[2]) | ((unsigned)f32_to_bf16(b[3]) << 16);
+  r[0] = pack2(a[0], a[1]);
+  r[1] = pack2(a[2], a[3]);
+  r[2] = pack2(b[0], b[1]);
+  r[3] = pack2(b[2], b[3]);
   return __builtin_bit_cast(bf16x8_t, r);
 }
+__device__ __forceinline__ u32x2 pack_row4(const f32x4& v) {
+  u32x2 w;
+  w[0] = pack2(v[0], v[1]);
+  w[1] = pack2(v[2], v[3]);
+  return w;
+}
 
+// Reductions over lane ^ 16 and lane ^ 32 through the gfx950 row / half swaps (v_permlane16_swap,
+// v_permlane32_swap): plain VALU instructions, no trip through the LDS crossbar. Swapping a value with
+// itself returns {rows 0,0,2,2 | rows 1,1,3,3} (16) and {lower half twice | upper half twice} (32).
+struct SwapPair { float x, y; };
+__device__ __forceinline__ SwapPair swap16(float v) {
+  const unsigned u = __float_as_uint(v);
+  const u32x2 r = __builtin_bit_cast(u32x2, __builtin_amdgcn_permlane16_swap(u, u, false, false));
+  const unsigned r0 = r[0], r1 = r[1];     // scalars first: a bit_cast of a vector element reads element 0
+  return {__uint_as_float(r0), __uint_as_float(r1)};
+}
+__device__ __forceinline__ SwapPair swap32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const u32x2 r = __builtin_bit_cast(u32x2, __builtin_amdgcn_permlane32_swap(u, u, false, false));
+  const unsigned r0 = r[0], r1 = r[1];
+  return {__uint_as_float(r0), __uint_as_float(r1)};
+}
 __device__ __forceinline__ float group_max(float v) {   // over the 4 lanes that share lane & 15
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+  const SwapPair a = swap16(v);
+  const SwapPair b = swap32(fmaxf(a.x, a.y));
+  return fmaxf(b.x, b.y);
 }
 __device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  const SwapPair a = swap16(v);
+  const SwapPair b = swap32(a.x + a.y);
+  return b.x + b.y;
 }
 
 // 64 rows x 64 bf16 of one (batch, head) starting at token t0, component `which` (0 q, 1 k, 2 v) of qkv,
@@ -121,7 +155,8 @@ __device__ __forceinline__ void store_tr_img(char* img, const TileRegs& r, int t
 }
 
 // ------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];   // [buf][K row image | V tr image]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -176,10 +211,9 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
       }
     // scale (+ key bias), online softmax per query column
     f32x4 kb[4];
+    if (BIAS) {
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-      kb[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.bias) {
+      for (int jb = 0; jb < 4; ++jb) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + (long long)b * a.S + t * KT + jb * 16 + g * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) kb[jb][r] = fmaxf(bv[r], -1e30f) * kLog2e;
@@ -193,19 +227,20 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
       for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s[jb][qb][r] = fmaf(s[jb][qb][r], c, kb[jb][r]);
+          if (BIAS) s[jb][qb][r] = fmaf(s[jb][qb][r], c, kb[jb][r]);
           mx = fmaxf(mx, s[jb][qb][r]);
         }
       mx = group_max(mx);
+      if (!BIAS) mx *= c;                  // c > 0: the maximum commutes with the scaling
       const float mn = fmaxf(m[qb], mx);
-      const float alpha = exp2f(m[qb] - mn);
+      const float alpha = fexp2(m[qb] - mn);
       m[qb] = mn;
       float sum = 0.f;
 #pragma unroll
       for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(s[jb][qb][r] - mn);
+          const float p = BIAS ? fexp2(s[jb][qb][r] - mn) : fexp2(fmaf(s[jb][qb][r], c, -mn));
           s[jb][qb][r] = p;
           sum += p;
         }
@@ -241,11 +276,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
     unsigned short* orow = a.out + ((long long)(b * a.S + q) * a.nh + h) * HD;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
-      const f32x4 v = o[db][qb] * inv;
-      u32x2 w;
-      w[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-      w[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-      *reinterpret_cast<u32x2*>(orow + db * 16 + g * 4) = w;
+      *reinterpret_cast<u32x2*>(orow + db * 16 + g * 4) = pack_row4(o[db][qb] * inv);
     }
     if (g == 0) a.lse[((long long)b * a.nh + h) * a.S + q] = m[qb] + log2f(lt);
   }
@@ -279,7 +310,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* _
 // Workgroup = 128 query rows of one (batch, head); loops over key tiles. Per tile: S^T = K Q^T and
 // dP^T = V dO^T (key on the accumulator row, query on the lane), P = exp2(S' - lse),
 // dS = P * (dP - delta) * scale, dQ^T += K^T dS^T with K fetched by transposing reads.
-__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(AttnArgs a) {
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 3 * 8192];   // [buf][K row | K tr | V row]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -324,52 +356,54 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(AttnArgs a) {
       kr = load_tile(kp, ld, (t + 1) * KT, tid);
       vr = load_tile(vp, ld, (t + 1) * KT, tid);
     }
-    f32x4 s[4][2], dp[4][2];
+    // two halves of 32 keys: the S / dP products of the second half are in flight on the matrix pipe while the
+    // vector unit turns the first half into dS, and the dQ products of the first half overlap the second's
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+    for (int hf = 0; hf < 2; ++hf) {
+      f32x4 s[2][2], dp[2][2];
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) { s[jb][qb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[jb][qb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+        for (int qb = 0; qb < 2; ++qb) { s[jj][qb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[jj][qb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const bf16x8_t kf = frag_row(kimg, jb * 16, ks, lane);
-        const bf16x8_t vf = frag_row(vimg, jb * 16, ks, lane);
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          s[jb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], s[jb][qb], 0, 0, 0);
-          dp[jb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qb][ks], dp[jb][qb], 0, 0, 0);
+        for (int jj = 0; jj < 2; ++jj) {
+          const bf16x8_t kf = frag_row(kimg, (hf * 2 + jj) * 16, ks, lane);
+          const bf16x8_t vf = frag_row(vimg, (hf * 2 + jj) * 16, ks, lane);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) {
+            s[jj][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], s[jj][qb], 0, 0, 0);
+            dp[jj][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qb][ks], dp[jj][qb], 0, 0, 0);
+          }
         }
+      bf16x8_t dsf[2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          f32x4 kb = {0.f, 0.f, 0.f, 0.f};
+          if (BIAS) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + (long long)b * a.S + t * KT + (hf * 2 + jj) * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kb[r] = fmaxf(bv[r], -1e30f) * kLog2e;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fexp2(fmaf(s[jj][qb][r], c, BIAS ? kb[r] - lse[qb] : -lse[qb]));
+            s[jj][qb][r] = p * (dp[jj][qb][r] - dl[qb]);     // dS / scale: the factor is applied to dQ once, at the end
+          }
+        }
+        dsf[qb] = pack_p(s[0][qb], s[1][qb]);
       }
-    bf16x8_t dsf[2][2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        f32x4 kb = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + (long long)b * a.S + t * KT + jb * 16 + g * 4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) kb[r] = fmaxf(bv[r], -1e30f) * kLog2e;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(fmaf(s[jb][qb][r], c, kb[r]) - lse[qb]);
-          s[jb][qb][r] = p * (dp[jb][qb][r] - dl[qb]) * a.scale;       // dS
-        }
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) dsf[qb][ks] = pack_p(s[2 * ks][qb], s[2 * ks + 1][qb]);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        const bf16x8_t kt = frag_tr(ktr, db * 16, ks, lane);
+        const bf16x8_t kt = frag_tr(ktr, db * 16, hf, lane);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
-          dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[qb][ks], dq[db][qb], 0, 0, 0);
+          dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[qb], dq[db][qb], 0, 0, 0);
       }
+    }
     if (t + 1 < nt) {
       char* nk = smem + ((t + 1) & 1) * 24576;
       store_row_img(nk, kr, tid);
@@ -384,11 +418,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(AttnArgs a) {
     unsigned short* row = dqp + (long long)(q0 + qb * 16 + fr) * ld;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
-      const f32x4 v = dq[db][qb];
-      u32x2 w;
-      w[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-      w[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-      *reinterpret_cast<u32x2*>(row + db * 16 + g * 4) = w;
+      *reinterpret_cast<u32x2*>(row + db * 16 + g * 4) = pack_row4(dq[db][qb] * a.scale);
     }
   }
 }
@@ -398,8 +428,10 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(AttnArgs a) {
 // KEY rides on the lane (second operand): S = Q K^T and dP = dO V^T give, per lane, one key and four
 // consecutive queries per 16-query block; P and dS are then the second operands of
 // dV^T += dO^T P and dK^T += Q^T dS, whose first operands are transposing reads of the dO and Q tiles.
-__global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * 8192];   // [buf][Q row | Q tr | dO row | dO tr]
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void flash_bwd_dkdv_kernel(AttnArgs a) {
+  // [buf][Q row | Q tr | dO row | dO tr], then [buf][lse of the 64 queries | delta of the 64 queries]
+  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * 8192 + 2 * 512];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * QB + wid * 32;
@@ -422,7 +454,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(AttnArgs a) {
       kf[kb][ks] = *reinterpret_cast<const bf16x8_t*>(kp + (long long)k * ld + ks * 32 + g * 8);
       vf[kb][ks] = *reinterpret_cast<const bf16x8_t*>(vp + (long long)k * ld + ks * 32 + g * 8);
     }
-    if (a.bias) kbias[kb] = fmaxf(a.bias[(long long)b * a.S + k], -1e30f) * kLog2e;
+    if (BIAS) kbias[kb] = fmaxf(a.bias[(long long)b * a.S + k], -1e30f) * kLog2e;
   }
   f32x4 dk[4][2], dv[4][2];
 #pragma unroll
@@ -431,11 +463,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(AttnArgs a) {
     for (int kb = 0; kb < 2; ++kb) { dk[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nt = a.S / KT;
+  // the per-query statistics ride along with the tiles: threads 0..15 fetch lse, 16..31 delta, four queries each,
+  // one tile ahead, so that their (global-memory) latency is hidden like the tiles' own
+  char* stat = smem + 2 * 4 * 8192;
+  const float* statp = (tid < 16 ? lsep : dlp) + (tid & 15) * 4;
   TileRegs qr = load_tile(qp, ld, 0, tid), dr = load_tile(dop, ldo, 0, tid);
+  f32x4 st = {0.f, 0.f, 0.f, 0.f};
+  if (tid < 32) st = *reinterpret_cast<const f32x4*>(statp);
   store_row_img(smem, qr, tid);
   store_tr_img(smem + 8192, qr, tid);
   store_row_img(smem + 16384, dr, tid);
   store_tr_img(smem + 24576, dr, tid);
+  if (tid < 32) *reinterpret_cast<f32x4*>(stat + tid * 16) = st;
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const char* qimg = smem + (t & 1) * 32768;
@@ -445,64 +484,67 @@ __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(AttnArgs a) {
     if (t + 1 < nt) {
       qr = load_tile(qp, ld, (t + 1) * KT, tid);
       dr = load_tile(dop, ldo, (t + 1) * KT, tid);
+      if (tid < 32) st = *reinterpret_cast<const f32x4*>(statp + (t + 1) * KT);
     }
-    // s[ib][kb]: lane = (key fr of block kb, queries t*64 + ib*16 + 4g + r)
-    f32x4 s[4][2], dp[4][2];
+    const char* stc = stat + (t & 1) * 512;
+    // two halves of 32 queries (see the dQ kernel); s[ii][kb]: lane = (key fr of block kb, queries
+    // t*64 + (2 hf + ii)*16 + 4g + r)
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
+    for (int hf = 0; hf < 2; ++hf) {
+      f32x4 s[2][2], dp[2][2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) { s[ib][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[ib][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+        for (int kb = 0; kb < 2; ++kb) { s[ii][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[ii][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-      for (int ib = 0; ib < 4; ++ib) {
-        const bf16x8_t qfr = frag_row(qimg, ib * 16, ks, lane);
-        const bf16x8_t dfr = frag_row(dimg, ib * 16, ks, lane);
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          s[ib][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kb][ks], s[ib][kb], 0, 0, 0);
-          dp[ib][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[kb][ks], dp[ib][kb], 0, 0, 0);
+        for (int ii = 0; ii < 2; ++ii) {
+          const bf16x8_t qfr = frag_row(qimg, (hf * 2 + ii) * 16, ks, lane);
+          const bf16x8_t dfr = frag_row(dimg, (hf * 2 + ii) * 16, ks, lane);
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            s[ii][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kb][ks], s[ii][kb], 0, 0, 0);
+            dp[ii][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[kb][ks], dp[ii][kb], 0, 0, 0);
+          }
         }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(stc + ((hf * 2 + ii) * 16 + g * 4) * 4);
+        const f32x4 de = *reinterpret_cast<const f32x4*>(stc + 256 + ((hf * 2 + ii) * 16 + g * 4) * 4);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fexp2(fmaf(s[ii][kb][r], c, BIAS ? kbias[kb] - ls[r] : -ls[r]));
+            s[ii][kb][r] = p;
+            dp[ii][kb][r] = p * (dp[ii][kb][r] - de[r]);      // dS / scale, applied to dK at the end
+          }
       }
-    bf16x8_t pf[2][2], dsf[2][2];
+      bf16x8_t pf[2], dsf[2];
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib) {
-      const f32x4 ls = *reinterpret_cast<const f32x4*>(lsep + t * KT + ib * 16 + g * 4);
-      const f32x4 de = *reinterpret_cast<const f32x4*>(dlp + t * KT + ib * 16 + g * 4);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(fmaf(s[ib][kb][r], c, kbias[kb]) - ls[r]);
-          s[ib][kb][r] = p;
-          dp[ib][kb][r] = p * (dp[ib][kb][r] - de[r]) * a.scale;
-        }
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        pf[kb][ks] = pack_p(s[2 * ks][kb], s[2 * ks + 1][kb]);
-        dsf[kb][ks] = pack_p(dp[2 * ks][kb], dp[2 * ks + 1][kb]);
+      for (int kb = 0; kb < 2; ++kb) {
+        pf[kb] = pack_p(s[0][kb], s[1][kb]);
+        dsf[kb] = pack_p(dp[0][kb], dp[1][kb]);
       }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        const bf16x8_t dot = frag_tr(dtr, db * 16, ks, lane);
-        const bf16x8_t qt = frag_tr(qtr, db * 16, ks, lane);
+        const bf16x8_t dot = frag_tr(dtr, db * 16, hf, lane);
+        const bf16x8_t qt = frag_tr(qtr, db * 16, hf, lane);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-          dv[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kb][ks], dv[db][kb], 0, 0, 0);
-          dk[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb][ks], dk[db][kb], 0, 0, 0);
+          dv[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kb], dv[db][kb], 0, 0, 0);
+          dk[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], dk[db][kb], 0, 0, 0);
         }
       }
+    }
     if (t + 1 < nt) {
       char* nq = smem + ((t + 1) & 1) * 32768;
       store_row_img(nq, qr, tid);
       store_tr_img(nq + 8192, qr, tid);
       store_row_img(nq + 16384, dr, tid);
       store_tr_img(nq + 24576, dr, tid);
+      if (tid < 32) *reinterpret_cast<f32x4*>(stat + ((t + 1) & 1) * 512 + tid * 16) = st;
     }
     __syncthreads();
   }
@@ -513,14 +555,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(AttnArgs a) {
     const long long off = (long long)(k0 + kb * 16 + fr) * ld;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
-      const f32x4 x = dk[db][kb], y = dv[db][kb];
-      u32x2 w, z;
-      w[0] = (unsigned)f32_to_bf16(x[0]) | ((unsigned)f32_to_bf16(x[1]) << 16);
-      w[1] = (unsigned)f32_to_bf16(x[2]) | ((unsigned)f32_to_bf16(x[3]) << 16);
-      z[0] = (unsigned)f32_to_bf16(y[0]) | ((unsigned)f32_to_bf16(y[1]) << 16);
-      z[1] = (unsigned)f32_to_bf16(y[2]) | ((unsigned)f32_to_bf16(y[3]) << 16);
-      *reinterpret_cast<u32x2*>(dkp + off + db * 16 + g * 4) = w;
-      *reinterpret_cast<u32x2*>(dvp + off + db * 16 + g * 4) = z;
+      *reinterpret_cast<u32x2*>(dkp + off + db * 16 + g * 4) = pack_row4(dk[db][kb] * a.scale);
+      *reinterpret_cast<u32x2*>(dvp + off + db * 16 + g * 4) = pack_row4(dv[db][kb]);
     }
   }
 }
@@ -537,7 +573,8 @@ DTF_API int dtf_flash_attn_fwd(const void* qkv, const float* bias, void* out, fl
   AttnArgs a = {};
   a.qkv = (const unsigned short*)qkv; a.bias = bias; a.out = (unsigned short*)out; a.lse = lse;
   a.B = B; a.S = S; a.nh = nh; a.scale = scale;
-  hipLaunchKernelGGL(flash_fwd_kernel, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
+  if (bias) hipLaunchKernelGGL(flash_fwd_kernel<true>, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(flash_fwd_kernel<false>, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -553,7 +590,12 @@ DTF_API int dtf_flash_attn_bwd(const void* qkv, const float* bias, const void* o
   a.qkv = (const unsigned short*)qkv; a.bias = bias; a.lse = const_cast<float*>(lse);
   a.dout = (const unsigned short*)dout; a.delta = delta; a.dqkv = (unsigned short*)dqkv;
   a.B = B; a.S = S; a.nh = nh; a.scale = scale;
-  hipLaunchKernelGGL(flash_bwd_dq_kernel, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(flash_bwd_dkdv_kernel, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
+  if (bias) {
+    hipLaunchKernelGGL(flash_bwd_dq_kernel<true>, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(flash_bwd_dkdv_kernel<true>, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(flash_bwd_dq_kernel<false>, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(flash_bwd_dkdv_kernel<false>, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
+  }
   return (int)hipGetLastError();
 }
