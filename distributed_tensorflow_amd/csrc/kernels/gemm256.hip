@@ -54,7 +54,9 @@ struct G256Args {
   int M, N, K;
   int bias_dtype, act;
   int tiles_m, tiles_n;
-  const unsigned short* Cin;   // optional bf16 tensor (indexed like C) added to the result
+  const unsigned short* Cin;   // optional bf16 tensor (indexed like C) combined with the result ...
+  int cin_mode;                // ... 1: added, 2: multiplied
+  unsigned short* C2;          // act 3: second output (indexed like C), the derivative of the activation
   float* W;              // fp32 slabs [splits][M][N] when splits > 1
   int k_per_split;       // multiple of TK
   int splits;
@@ -88,7 +90,30 @@ __device__ __forceinline__ bf16x8_t frag256(const char* half, int row0, int ks, 
   }
 }
 
-__device__ __forceinline__ float gelu_erf256(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// GELU (erf form) and its derivative for bf16 outputs, sized for an epilogue that handles 128 elements per lane:
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) through the rational approximation erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3) e^{-z^2},
+// t = 1 / (1 + p z) (Abramowitz & Stegun 7.1.25, |error| <= 2.5e-5, far below bf16 resolution). With z = |x| / sqrt 2
+// the exponential is e^{-x^2 / 2}, the same one the density phi(x) of the derivative needs: one v_exp_f32 and one
+// v_rcp_f32 per element instead of the branchy library erff.
+//   gelu(x) = x Phi(x),   gelu'(x) = Phi(x) + x phi(x)
+// Not inlined: spread over the 128 unrolled elements of the epilogue its temporaries push the kernel (already at
+// 240-255 registers) into scratch spills that slow every variant down by 15-30 %.
+// Two elements per call so that the polynomial runs on packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32).
+typedef float f32x2_256 __attribute__((ext_vector_type(2)));
+__device__ __noinline__ f32x4 gelu_pair256(f32x2_256 x) {        // -> {gelu(x0), gelu(x1), gelu'(x0), gelu'(x1)}
+  const f32x2_256 xx = x * x * -0.72134752044448170f;
+  const f32x2_256 e = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};          // e^{-x^2/2}
+  const f32x2_256 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2_256 den = ax * (0.47047f * 0.70710678118654752f) + 1.f;
+  const f32x2_256 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  // half of the polynomial: hq = 0.5 (1 - erf(|x| / sqrt 2))
+  const f32x2_256 hq = t * ((t * (0.5f * 0.7478556f) + 0.5f * -0.0958798f) * t + 0.5f * 0.3480242f) * e;
+  const f32x2_256 one_m = 1.f - hq;
+  const f32x2_256 cdf = {x[0] >= 0.f ? one_m[0] : hq[0], x[1] >= 0.f ? one_m[1] : hq[1]};
+  const f32x2_256 h = x * cdf;
+  const f32x2_256 d = x * 0.3989422804014327f * e + cdf;
+  return f32x4{h[0], h[1], d[0], d[1]};
+}
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -315,57 +340,112 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
     // spare LDS and writes 64-byte row segments with 16-byte stores. The activation and the accumulate
     // input are compile-time choices of the body: tested per element they cost a branch (and the
     // instruction fetch of the skipped code) 128 times per lane.
+    // The epilogue's indices are re-derived from values the compiler cannot trace back past this point: otherwise
+    // it hoists the epilogue's address arithmetic above the main loop, where the extra live registers spill.
+    int cm0e = cm0, cn0e = cn0, lane_e = lane;
+    asm volatile("" : "+s"(cm0e), "+s"(cn0e), "+v"(lane_e));
+    const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
     char* blk = smem + kLds256 + wid * 4096;
     auto epilogue = [&](auto act_c, auto cin_c) {
-      constexpr int ACT = decltype(act_c)::value;
-      constexpr bool CIN = decltype(cin_c)::value;
+      constexpr int ACT = decltype(act_c)::value;     // 0 none, 1 relu, 2 gelu, 3 gelu + its derivative into C2
+      constexpr int CIN = decltype(cin_c)::value;     // 0 none, 1 add Cin, 2 multiply by Cin
+      // The combine input comes in by LDS-DMA, all 16 KiB of the wave's four quadrants at once, into the operand
+      // buffers the main loop no longer needs: one exposed fetch latency instead of one per quadrant, and no
+      // registers (holding even one quadrant ahead in registers spills). Only when no next tile's prologue
+      // owns those buffers, i.e. one workgroup per tile; the persistent grid keeps the per-store fetch.
+      // Full tiles only (no clamping of edge addresses): a wave-uniform base per 16-row slice plus ONE per-lane_e
+      // 32-bit offset, so the 16 fetches cost no address registers either.
+      const bool cin_dma = CIN != 0 && next >= nwg && (int)gridDim.x >= nwg && cm0e + TM <= g.M && cn0e + TN <= g.N;
+      char* cbuf = smem + wid * 16384;
+      if (CIN != 0 && cin_dma) {
+        __syncthreads();          // every wave has read its last operand fragments
+        const int wu = __builtin_amdgcn_readfirstlane(wid);
+        const unsigned short* wbase = g.Cin + (long long)(cm0e + (wu >> 2) * 64) * g.ldc + cn0e + (wu & 3) * 32;
+        const unsigned lane_off = (unsigned)(lane_e >> 2) * (unsigned)g.ldc + (unsigned)(lane_e & 3) * 8u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const unsigned short* sbase = wbase + (long long)((q >> 1) * 128 + v * 16) * g.ldc + (q & 1) * 128;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sbase + lane_off),
+                                             (lds_ptr_t)(smem + wu * 16384 + q * 4096 + v * 1024), 16, 0, 0);
+          }
+      }
 #pragma unroll
       for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
         for (int qj = 0; qj < 2; ++qj) {
+          u32x2 side[ACT == 3 ? 8 : 1];
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               f32x4 v = acc[qi * 4 + i][qj * 2 + j];
-              if (ACT != 0) {
+              if (ACT == 3) {
+                const f32x4 lo = gelu_pair256(f32x2_256{v[0], v[1]}), hi = gelu_pair256(f32x2_256{v[2], v[3]});
+                v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                const f32x4 d = {lo[2], lo[3], hi[2], hi[3]};
+                side[i * 2 + j][0] = (unsigned)f32_to_bf16(d[0]) | ((unsigned)f32_to_bf16(d[1]) << 16);
+                side[i * 2 + j][1] = (unsigned)f32_to_bf16(d[2]) | ((unsigned)f32_to_bf16(d[3]) << 16);
+              } else if (ACT == 2) {
+                const f32x4 lo = gelu_pair256(f32x2_256{v[0], v[1]}), hi = gelu_pair256(f32x2_256{v[2], v[3]});
+                v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+              } else if (ACT == 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = ACT == 1 ? fmaxf(v[r], 0.f) : gelu_erf256(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
               }
               u32x2 o;
               o[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
               o[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-              *reinterpret_cast<u32x2*>(blk + (i * 16 + fr) * 64 + j * 32 + fq * 8) = o;
+              *reinterpret_cast<u32x2*>(blk + (i * 16 + fr_e) * 64 + j * 32 + fq_e * 8) = o;
             }
           // the staging block is private to the wave: LDS operations of one wave execute in order
+          if (CIN != 0 && cin_dma && qi == 0 && qj == 0) WAIT_VM(0);
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int idx = v * 64 + lane;
-            const int row = idx >> 2, c16 = idx & 3;
-            const int m = cm0 + qi * 128 + wr * 64 + row;
-            const int n = cn0 + qj * 128 + wc * 32 + c16 * 8;
-            u32x4 val = *reinterpret_cast<const u32x4*>(blk + row * 64 + c16 * 16);
-            if (m < g.M && n < g.N) {
-              if (CIN) {
-                // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
-                const u32x4 ci = *reinterpret_cast<const u32x4*>(g.Cin + (long long)m * g.ldc + n);
+          for (int pass = 0; pass < (ACT == 3 ? 2 : 1); ++pass) {
+            if (pass == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(ci[e] << 16);
-                  const float hi = __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(ci[e] & 0xffff0000u);
-                  val[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                  *reinterpret_cast<u32x2*>(blk + (i * 16 + fr_e) * 64 + j * 32 + fq_e * 8) = side[ACT == 3 ? i * 2 + j : 0];
+            }
+            unsigned short* dst = pass == 0 ? g.C : g.C2;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int idx = v * 64 + lane_e;
+              const int row = idx >> 2, c16 = idx & 3;
+              const int m = cm0e + qi * 128 + wr * 64 + row;
+              const int n = cn0e + qj * 128 + wc * 32 + c16 * 8;
+              u32x4 val = *reinterpret_cast<const u32x4*>(blk + row * 64 + c16 * 16);
+              if (m < g.M && n < g.N) {
+                if (CIN != 0) {
+                  // out = bf16(bf16(acc) (+|*) C_in): the rounding of an unfused GEMM followed by an elementwise kernel
+                  const u32x4 ci = cin_dma ? *reinterpret_cast<const u32x4*>(cbuf + (qi * 2 + qj) * 4096 + idx * 16)
+                                           : *reinterpret_cast<const u32x4*>(g.Cin + (long long)m * g.ldc + n);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float a0 = __uint_as_float(val[e] << 16), a1 = __uint_as_float(val[e] & 0xffff0000u);
+                    const float c0 = __uint_as_float(ci[e] << 16), c1 = __uint_as_float(ci[e] & 0xffff0000u);
+                    const float lo = CIN == 1 ? a0 + c0 : a0 * c0;
+                    const float hi = CIN == 1 ? a1 + c1 : a1 * c1;
+                    val[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                  }
                 }
+                *reinterpret_cast<u32x4*>(dst + (long long)m * g.ldc + n) = val;
               }
-              *reinterpret_cast<u32x4*>(g.C + (long long)m * g.ldc + n) = val;
             }
           }
-        }
+      }
     };
     using std::integral_constant;
-    if (g.Cin) epilogue(integral_constant<int, 0>{}, integral_constant<bool, true>{});
-    else if (g.act == 0) epilogue(integral_constant<int, 0>{}, integral_constant<bool, false>{});
-    else if (g.act == 1) epilogue(integral_constant<int, 1>{}, integral_constant<bool, false>{});
-    else epilogue(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+    if (g.Cin) {
+      if (g.cin_mode == 2) epilogue(integral_constant<int, 0>{}, integral_constant<int, 2>{});
+      else epilogue(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+    } else if (g.act == 0) epilogue(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    else if (g.act == 1) epilogue(integral_constant<int, 1>{}, integral_constant<int, 0>{});
+    else if (g.act == 2) epilogue(integral_constant<int, 2>{}, integral_constant<int, 0>{});
+    else epilogue(integral_constant<int, 3>{}, integral_constant<int, 0>{});
     if (stamp && it == (int)blockIdx.x) {
       g.stamps[blockIdx.x * 4 + 2] = wall_clock64() - g.stamps[blockIdx.x * 4 + 2];   // issue time of the epilogue
       WAIT_VM(0);
@@ -391,12 +471,14 @@ extern "C" int dtf_splitk_reduce(const float* W, void* C, const void* bias, int 
 
 // C (bf16, row-major, ldc) = act(op(A) * op(B) + bias). layout 0 NT: A[M,K] B[N,K]; 1 NN: A[M,K] B[K,N];
 // 2 TN: A[K,M] B[K,N]. Requirements: K % 64 == 0, N % 8 == 0 (M % 8 == 0 for TN), leading dimensions % 8 == 0,
-// 16-byte aligned bases, at least 8 rows / columns per operand. act: 0 none, 1 relu, 2 gelu(erf).
-// splits > 1: workspace holds splits * M * N floats. cin: optional bf16 tensor laid out like C, added to the result. Returns -9 when the shape does not qualify
-// (the caller then uses dtf_gemm_bf16).
-DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
-                        long long lda, long long ldb, long long ldc, int bias_dtype, int act, int splits,
-                        void* workspace, const void* cin, hipStream_t stream) {
+// 16-byte aligned bases, at least 8 rows / columns per operand. act: 0 none, 1 relu, 2 gelu(erf), 3 gelu(erf)
+// with gelu'(pre-activation) written to c2 (laid out like C; what the backward pass multiplies by).
+// splits > 1: workspace holds splits * M * N floats. cin: optional bf16 tensor laid out like C, added to
+// (cin_mode 1) or multiplied into (cin_mode 2) the result. Returns -9 when the shape does not qualify (the
+// caller then uses dtf_gemm_bf16).
+DTF_API int dtf_gemm256_ex(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                           long long lda, long long ldb, long long ldc, int bias_dtype, int act, int splits,
+                           void* workspace, const void* cin, int cin_mode, void* c2, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (K % TK || N % 8 || lda % 8 || ldb % 8 || ldc % 8 || M < 8 || N < 8) return -9;
   if (layout == 2 && M % 8) return -9;
@@ -416,8 +498,11 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
     }
     attr_set = true;
   }
-  if (splits < 1 || cin) splits = 1;               // slabs do not carry the accumulate input
+  if (splits < 1 || cin || act == 3) splits = 1;   // slabs do not carry the accumulate input / the second output
   if (cin && act != 0) return -9;                  // the accumulate epilogue has no activation
+  if (cin && cin_mode != 1 && cin_mode != 2) return -1;
+  if (act == 3 && (!c2 || splits != 1)) return -9; // the derivative output is written by the in-kernel epilogue only
+  if (act < 0 || act > 3) return -1;
   int kps = ((K + splits - 1) / splits + TK - 1) / TK * TK;
   splits = (K + kps - 1) / kps;
   if (splits > 1 && !workspace) return -3;
@@ -426,6 +511,7 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias_dtype = bias_dtype; g.act = act;
   g.tiles_m = (M + TM - 1) / TM; g.tiles_n = (N + TN - 1) / TN;
   g.W = (float*)workspace; g.k_per_split = kps; g.splits = splits; g.Cin = (const unsigned short*)cin;
+  g.cin_mode = cin ? cin_mode : 0; g.C2 = (unsigned short*)c2;
   g.stamps = g_stamps256;
   // persistent: one workgroup per CU (the kernel takes the whole LDS), each walking its share of tiles
   const int nwg = g.tiles_m * g.tiles_n;
@@ -439,6 +525,13 @@ DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const
   }
   if (splits > 1) return dtf_splitk_reduce((const float*)workspace, C, bias, bias_dtype, act, 0, splits, M, N, ldc, stream);
   return (int)hipGetLastError();
+}
+
+DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                        long long lda, long long ldb, long long ldc, int bias_dtype, int act, int splits,
+                        void* workspace, const void* cin, hipStream_t stream) {
+  return dtf_gemm256_ex(layout, A, B, C, bias, M, N, K, lda, ldb, ldc, bias_dtype, act, splits, workspace, cin, 1,
+                        nullptr, stream);
 }
 
 DTF_API int dtf_gemm256_nt(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, long long lda,

@@ -82,8 +82,8 @@ class EncoderLayer(nn.Module):
         qkv, xr = dense_ops.linear_fork(x, self.qkv.weight, self.qkv.bias)
         ctxv = attn_ops.self_attention(qkv.view(B, S, 3, self.heads, H // self.heads), key_bias).view(B, S, H)
         x = self.ln1(self.proj(ctxv), residual=xr)
-        f, xr = dense_ops.linear_fork(x, self.ffn1.weight, self.ffn1.bias, "gelu")
-        return self.ln2(self.ffn2(f), residual=xr)
+        f, xr = dense_ops.ffn_fork(x, self.ffn1.weight, self.ffn1.bias, self.ffn2.weight, self.ffn2.bias)
+        return self.ln2(f, residual=xr)
 
 
 class Bert(Model):

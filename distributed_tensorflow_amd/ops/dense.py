@@ -101,6 +101,67 @@ class _LinearForkFn(_LinearFn):
         return _LinearFn.backward(ctx, gy, g_alias)
 
 
+class _FfnForkFn(torch.autograd.Function):
+    """``(gelu(x W1^T + b1) W2^T + b2, alias of x)`` as one node, so that the GELU never runs as a kernel of
+    its own: the first GEMM's epilogue writes ``h = gelu(pre)`` and ``d = gelu'(pre)``, and the data-gradient
+    GEMM of the second layer multiplies by ``d`` in its epilogue. The alias carries the residual branch's
+    gradient into the first layer's data-gradient epilogue (see :class:`_LinearForkFn`)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M, H, Fd = x2.shape[0], x2.shape[1], w1.shape[0]
+        h = torch.empty((M, Fd), dtype=torch.bfloat16, device=x.device)
+        d = torch.empty_like(h)
+        _gemm.gemm256(_gemm.NT, x2, w1, M, Fd, H, bias=b1, activation="gelu", out=h, grad_out=d)
+        y = _gemm.gemm_nt(h, w2, bias=b2)
+        ctx.x_shape = x.shape
+        ctx.bias_dtypes = (b1.dtype, b2.dtype)
+        ctx.save_for_backward(x2, w1, w2, h, d)
+        return y.reshape(*x.shape[:-1], w2.shape[0]), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, g_alias):
+        x2, w1, w2, h, d = ctx.saved_tensors
+        if gy is None:
+            return g_alias, None, None, None, None
+        g2 = gy.reshape(-1, gy.shape[-1]).contiguous()
+        M, Fd = h.shape
+        gw2 = _gemm.gemm_tn(g2, h) if ctx.needs_input_grad[3] else None
+        gb2 = _gemm.col_sum(g2, dtype=ctx.bias_dtypes[1]) if ctx.needs_input_grad[4] else None
+        g1 = _gemm.gemm256(_gemm.NN, g2, w2, M, Fd, g2.shape[1], mul=d)            # (g2 W2) * gelu'(pre)
+        gw1 = _gemm.gemm_tn(g1, x2) if ctx.needs_input_grad[1] else None
+        gb1 = _gemm.col_sum(g1, dtype=ctx.bias_dtypes[0]) if ctx.needs_input_grad[2] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            add = None
+            if g_alias is not None and g_alias.dtype == torch.bfloat16 and g_alias.is_contiguous() \
+                    and g_alias.data_ptr() % 16 == 0:
+                add, g_alias = g_alias.reshape(-1, g_alias.shape[-1]), None
+            gx = _gemm.gemm_nn(g1, w1, add=add).reshape(ctx.x_shape)
+            if g_alias is not None:
+                gx = gx + g_alias
+        return gx, gw1, gb1, gw2, gb2
+
+
+def ffn_fork(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
+    """``(linear(gelu(linear(x, w1, b1)), w2, b2), x')`` -- the transformer feed-forward block with ``x'`` an
+    alias of ``x`` for the residual branch. Large bf16 GPU shapes run as one autograd node with the GELU and
+    its derivative inside the GEMM epilogues; anything else is the composition of :func:`linear_fork` and
+    :func:`linear`."""
+    M = x.numel() // x.shape[-1]
+    H, Fd = x.shape[-1], w1.shape[0]
+    if (x.is_cuda and x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+            and b1 is not None and b2 is not None and x.requires_grad and torch.is_grad_enabled()
+            and _gemm.supported(x, w1) and w2.shape == (H, Fd) and w2.is_contiguous() and w1.is_contiguous()
+            and _gemm.big_ok(M, Fd, H) and _gemm.big_ok(M, Fd, w2.shape[0])):
+        return _FfnForkFn.apply(x, w1, b1, w2, b2)
+    f, xr = linear_fork(x, w1, b1, "gelu")
+    return linear(f, w2, b2), xr
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
            activation: str | None = None, dropout_p: float = 0.0, training: bool = False) -> torch.Tensor:
     """``dropout(act(x @ weight.T + bias))`` with ``weight`` in torch ``(out, in)`` layout. On the bf16

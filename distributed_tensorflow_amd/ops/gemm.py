@@ -153,19 +153,37 @@ def _big_ok(M: int, N: int, K: int) -> bool:
 
 
 def gemm256(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, bias=None, activation=None,
-            out=None, splits: int = 1, add: torch.Tensor | None = None) -> torch.Tensor:
+            out=None, splits: int = 1, add: torch.Tensor | None = None, mul: torch.Tensor | None = None,
+            grad_out: torch.Tensor | None = None) -> torch.Tensor:
     """``act(op(a) @ op(b) + bias)`` on the 256x256x64 LDS-DMA kernel (``csrc/kernels/gemm256.hip``);
-    layouts as in this module (NT, NN, TN). ``splits`` > 1 splits the contraction (weight gradients)."""
+    layouts as in this module (NT, NN, TN). ``splits`` > 1 splits the contraction (weight gradients).
+    ``add`` / ``mul``: bf16 tensor laid out like the result, added to / multiplied into it in the epilogue.
+    ``grad_out`` (with ``activation="gelu"``): receives ``gelu'(pre-activation)``."""
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     bias_dtype = _lib.dtype_code(bias.dtype) if bias is not None else 0
     ws = _workspace(a.device, splits * M * N) if splits > 1 else None
-    rc = _lib.kernels().dtf_gemm256(layout, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(bias), M, N, K,
-                                    ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
-                                    ctypes.c_longlong(out.stride(0)), bias_dtype, _ACT[activation], splits,
-                                    _lib.ptr(ws), _lib.ptr(add), _lib.stream_ptr(a.device))
+    act = _ACT[activation]
+    if grad_out is not None:
+        if activation != "gelu" or grad_out.shape != out.shape or grad_out.stride() != out.stride() \
+                or grad_out.dtype != torch.bfloat16:
+            raise ValueError("gemm256: grad_out needs activation='gelu' and the layout of the output")
+        act = 3
+    if add is not None and mul is not None:
+        raise ValueError("gemm256: add= and mul= are exclusive")
+    cin = add if add is not None else mul
+    rc = _lib.kernels().dtf_gemm256_ex(layout, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(bias), M, N, K,
+                                       ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
+                                       ctypes.c_longlong(out.stride(0)), bias_dtype, act, splits,
+                                       _lib.ptr(ws), _lib.ptr(cin), 2 if mul is not None else 1, _lib.ptr(grad_out),
+                                       _lib.stream_ptr(a.device))
     _lib.check(rc, "gemm256")
     return out
+
+
+def big_ok(M: int, N: int, K: int) -> bool:
+    """True when an ``[M, K] x [K, N]`` product is routed to the 256x256 kernel (and its fused epilogues exist)."""
+    return _big_ok(M, N, K)
 
 
 def gemm256_nt(a: torch.Tensor, b: torch.Tensor, bias=None, activation=None, out=None) -> torch.Tensor:

@@ -227,6 +227,10 @@ def test_custom_strategy_on_peer_pointer_allreduce_matches_single_process():
 
 # --------------------- every collective strategy with two ranks that share the GPU (gloo carries GPU tensors)
 def _strategy_worker(rank, world, port, kind, q):
+    import faulthandler
+    dump_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    dump = open(os.path.join(dump_dir, f"hang_{kind}_{rank}.txt"), "w") if os.path.isdir(dump_dir) else sys.stderr
+    faulthandler.dump_traceback_later(90, exit=True, file=dump)      # a hung rank reports where and ends
     try:
         from distributed_tensorflow_amd.comm.backend import Comm
         from distributed_tensorflow_amd.engine.optimizer import Adam

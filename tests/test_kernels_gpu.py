@@ -450,7 +450,7 @@ def test_dense_fused_dropout_matches_philox_reference(activation):
     yr = a * keep / (1 - p)
     yr.backward(gy.float())
     assert torch.equal((y != 0), (yr.bfloat16() != 0)) or float(((y != 0) != (yr != 0)).float().mean()) < 2e-3
-    assert torch.allclose(y.float(), yr, atol=0.06, rtol=0.03)
+    assert torch.allclose(y.float(), yr.detach(), atol=0.06, rtol=0.03)
     assert torch.allclose(x.grad.float(), xr.grad, atol=0.15, rtol=0.05)
     assert torch.allclose(w.grad.float(), wr.grad, atol=0.5, rtol=0.05)
     assert torch.allclose(b.grad.float(), br.grad, atol=0.3, rtol=0.05)
@@ -701,3 +701,30 @@ def test_linear_fork_accumulates_residual_gradient(M):
         res[fork] = [t.grad.float() for t in (x1, w1, b1)]
     for a, r in zip(res[True], res[False]):
         assert torch.allclose(a, r, atol=0.03 * float(r.abs().max()) + 1e-3, rtol=3e-2)
+
+
+@pytest.mark.parametrize("M", [4096, 8192])
+def test_ffn_fork_fused_gelu_epilogues_match_fp32_reference(M):
+    """The transformer feed-forward block with GELU and its derivative inside the 256x256 GEMM epilogues."""
+    from distributed_tensorflow_amd.ops import dense, gemm
+    torch.manual_seed(M + 1)
+    H, Fd = 512, 4096
+    assert gemm.big_ok(M, Fd, H)
+    x = torch.randn(M, H, device=DEV).bfloat16()
+    w1 = (torch.randn(Fd, H, device=DEV) * 0.05).bfloat16()
+    b1 = (torch.randn(Fd, device=DEV) * 0.1).bfloat16()
+    w2 = (torch.randn(H, Fd, device=DEV) * 0.03).bfloat16()
+    b2 = (torch.randn(H, device=DEV) * 0.1).bfloat16()
+    ts = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y, xi = dense.ffn_fork(*ts)
+    assert type(y.grad_fn).__name__ == "_FfnForkFnBackward"
+    gy = torch.randn_like(y)
+    ((y.float() * gy.float()).sum() + (xi.float() * 2.0).cos().sum()).backward()
+    rs = [t.float().clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    pre = rs[0] @ rs[1].t() + rs[2]
+    yr = torch.nn.functional.gelu(pre) @ rs[3].t() + rs[4]
+    ((yr * gy.float()).sum() + (rs[0] * 2.0).cos().sum()).backward()
+    assert torch.allclose(y.float(), yr.detach(), atol=0.02 * float(yr.detach().abs().max()), rtol=3e-2)
+    for a, r in zip(ts, rs):
+        assert torch.allclose(a.grad.float(), r.grad, atol=0.03 * float(r.grad.abs().max()) + 1e-3, rtol=5e-2), \
+            float((a.grad.float() - r.grad).abs().max())
