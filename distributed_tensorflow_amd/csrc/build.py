@@ -82,9 +82,20 @@ def build_kernels(jobs: int = 8, force: bool = False) -> Path:
              "-ffast-math", "-fno-finite-math-only", "-munsafe-fp-atomics", f"-I{kdir}"]
     objs = _compile_objects(srcs, headers, flags, "k", jobs)
     LIB_DIR.mkdir(parents=True, exist_ok=True)
-    if force or any(_newer(o, [], out) for o in objs):
+    if force or any(_newer(o, [], out) for o in objs) or _manifest_changed("k", objs):
         _run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(out), *map(str, objs)])
     return out
+
+
+def _manifest_changed(tag: str, objs: list[Path]) -> bool:
+    """True (and records the new list) when the set of objects that make up a library changed, e.g. a source
+    file was removed: no object is then newer than the library, but it must be linked again."""
+    mf = OBJ_DIR / f"{tag}_manifest.txt"
+    want = "\n".join(sorted(o.name for o in objs))
+    if mf.exists() and mf.read_text() == want:
+        return False
+    mf.write_text(want)
+    return True
 
 
 def build_runtime(jobs: int = 8, force: bool = False) -> Path:

@@ -728,3 +728,4 @@ def test_ffn_fork_fused_gelu_epilogues_match_fp32_reference(M):
     for a, r in zip(ts, rs):
         assert torch.allclose(a.grad.float(), r.grad, atol=0.03 * float(r.grad.abs().max()) + 1e-3, rtol=5e-2), \
             float((a.grad.float() - r.grad).abs().max())
+

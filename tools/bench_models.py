@@ -52,6 +52,11 @@ def main():
         st = MirroredStrategy(bert_base(512), comm, cfg, optimizer=Adam(learning_rate=1e-4))
         x, y = synthetic_mlm_batch(a.bert_batch, 512, 30522, DEV, n_pred=80)
         out.append(run("bert-base-mlm-seq512", st, x, y, a.steps, a.warmup, a.bert_batch, "sequences_per_s"))
+        try:
+            out.append(run("bert-base-mlm-seq512", st, x, y, a.steps, a.warmup, a.bert_batch, "sequences_per_s", True))
+        except Exception as e:  # a step that cannot be captured is reported, not fatal
+            out.append({"model": "bert-base-mlm-seq512", "hip_graph": True, "error": str(e)[:300]})
+            print(out[-1], flush=True)
         del st
     if "resnet20" in a.models:
         from distributed_tensorflow_amd.models.resnet import resnet20
