@@ -106,6 +106,14 @@ class Comm:
             return None
         if self.composed:
             n = inp.numel()
+            if inp.is_cuda:
+                # gloo's device all-gather was seen to hang with several ranks on one GPU (both ranks inside the
+                # call): stage through host memory, which is what gloo does internally for the other collectives
+                src = inp.cpu()
+                parts = [torch.empty_like(src) for _ in range(self.world)]
+                dist.all_gather(parts, src, group=self.group)
+                out[: n * self.world].copy_(torch.cat(parts))
+                return None
             chunks = [out[i * n:(i + 1) * n] for i in range(self.world)]
             src = inp.clone() if inp.data_ptr() == chunks[self.rank].data_ptr() else inp
             return dist.all_gather(chunks, src, group=self.group, async_op=async_op)

@@ -226,12 +226,19 @@ def test_custom_strategy_on_peer_pointer_allreduce_matches_single_process():
 
 
 # --------------------- every collective strategy with two ranks that share the GPU (gloo carries GPU tensors)
-def _strategy_worker(rank, world, port, kind, q):
+_KINDS = ["keras", "custom-ring", "sync", "async", "graph"]
+
+
+def _strategy_worker(rank, world, port, kinds, q):
+    """One rank; runs every strategy in turn over ONE process group (a pair of processes for all five keeps the
+    number of GPU contexts that come and go on the shared device small)."""
     import faulthandler
     dump_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    dump = open(os.path.join(dump_dir, f"hang_{kind}_{rank}.txt"), "w") if os.path.isdir(dump_dir) else sys.stderr
-    faulthandler.dump_traceback_later(90, exit=True, file=dump)      # a hung rank reports where and ends
+    dump = open(os.path.join(dump_dir, f"hang_strategies_{rank}.txt"), "w") if os.path.isdir(dump_dir) else sys.stderr
+    faulthandler.dump_traceback_later(150, exit=True, file=dump)      # a hung rank reports where and ends
+    out = {}
     try:
+        import numpy as np
         from distributed_tensorflow_amd.comm.backend import Comm
         from distributed_tensorflow_amd.engine.optimizer import Adam
         from distributed_tensorflow_amd.engine.replica import TrainConfig
@@ -241,59 +248,77 @@ def _strategy_worker(rank, world, port, kind, q):
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
         comm = Comm.init(rank, world, dev, master_port=port, timeout_s=60, backend="gloo")
-        torch.manual_seed(0)
-        cfg = TrainConfig(loss_reduction="mean", seed=0, bucket_bytes=256 << 10, first_bucket_bytes=64 << 10)
-        model = reference_mlp(dropout=0.0)
-        if kind == "keras":
-            st = mirrored.MirroredStrategy(model, comm, cfg, optimizer=Adam(1e-3))
-        elif kind == "custom-ring":
-            st = mirrored.CustomAllReduceStrategy(model, comm, cfg, optimizer=Adam(1e-3), algorithm="ring")
-        elif kind == "sync":
-            st = ps.SyncPSStrategy(model, comm, cfg, optimizer=Adam(1e-3))
-        elif kind == "async":
-            st = ps.AsyncPSStrategy(model, comm, cfg, optimizer=Adam(1e-3))
-        else:
-            st = mirrored.GraphStrategy(model, comm, cfg, optimizer=Adam(1e-3), degree=1)
         g = torch.Generator().manual_seed(7)
         xs = torch.rand(6, 32 * world, 28, 28, 1, generator=g)
         ys = torch.randint(0, 10, (6, 32 * world), generator=g)
-        losses = []
-        for i in range(6):
-            x = xs[i, rank * 32:(rank + 1) * 32].to(dev)
-            y = ys[i, rank * 32:(rank + 1) * 32].to(dev)
-            losses.append(float(st.train_step(x, y)))
-        st.finalize()
-        torch.cuda.synchronize()
-        import numpy as np
-        w = np.concatenate([a.reshape(-1) for a in st.replica.model.get_weights()])
-        q.put((rank, {"w": w, "losses": losses}))
+        for kind in kinds:
+            try:
+                torch.manual_seed(0)
+                cfg = TrainConfig(loss_reduction="mean", seed=0, bucket_bytes=256 << 10, first_bucket_bytes=64 << 10)
+                model = reference_mlp(dropout=0.0)
+                if kind == "keras":
+                    st = mirrored.MirroredStrategy(model, comm, cfg, optimizer=Adam(1e-3))
+                elif kind == "custom-ring":
+                    st = mirrored.CustomAllReduceStrategy(model, comm, cfg, optimizer=Adam(1e-3), algorithm="ring")
+                elif kind == "sync":
+                    st = ps.SyncPSStrategy(model, comm, cfg, optimizer=Adam(1e-3))
+                elif kind == "async":
+                    st = ps.AsyncPSStrategy(model, comm, cfg, optimizer=Adam(1e-3))
+                else:
+                    st = mirrored.GraphStrategy(model, comm, cfg, optimizer=Adam(1e-3), degree=1)
+                losses = []
+                for i in range(6):
+                    x = xs[i, rank * 32:(rank + 1) * 32].to(dev)
+                    y = ys[i, rank * 32:(rank + 1) * 32].to(dev)
+                    losses.append(float(st.train_step(x, y)))
+                st.finalize()
+                torch.cuda.synchronize()
+                w = np.concatenate([a.reshape(-1) for a in st.replica.model.get_weights()])
+                out[kind] = {"w": w, "losses": losses}
+                comm.barrier()
+                del st
+            except Exception as e:  # pragma: no cover
+                import traceback
+                out[kind] = {"error": f"{e}\n{traceback.format_exc()}"}
+                break               # the ranks are out of step from here on
+        q.put((rank, out))
         comm.barrier()
         comm.shutdown()
     except Exception as e:  # pragma: no cover
         import traceback
-        q.put((rank, {"error": f"{e}\n{traceback.format_exc()}"}))
+        out["init"] = {"error": f"{e}\n{traceback.format_exc()}"}
+        q.put((rank, out))
 
 
-@pytest.mark.parametrize("kind", ["keras", "custom-ring", "sync", "async", "graph"])
-def test_collective_strategies_two_ranks_on_one_gpu(kind):
-    import numpy as np
+@pytest.fixture(scope="module")
+def two_rank_results():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29680 + ["keras", "custom-ring", "sync", "async", "graph"].index(kind)
-    procs = [ctx.Process(target=_strategy_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    procs = [ctx.Process(target=_strategy_worker, args=(r, world, 29680, _KINDS, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
     try:
         for _ in range(world):
-            r, res = q.get(timeout=110)
+            r, res = q.get(timeout=170)
             got[r] = res
     finally:
         for p in procs:
             p.join(timeout=20)
             if p.is_alive():
                 p.kill()
+    return got
+
+
+@pytest.mark.parametrize("kind", _KINDS)
+def test_collective_strategies_two_ranks_on_one_gpu(kind, two_rank_results):
+    import numpy as np
+    world = 2
+    for r in range(world):
+        assert "init" not in two_rank_results[r], two_rank_results[r]["init"]["error"]
+        assert kind in two_rank_results[r], f"rank {r} stopped before {kind}: {list(two_rank_results[r])}"
+    got = {r: two_rank_results[r][kind] for r in range(world)}
     for r, res in got.items():
         assert "error" not in res, res.get("error")
     assert np.allclose(got[0]["w"], got[1]["w"], atol=1e-6)          # replicas agree after finalize()
