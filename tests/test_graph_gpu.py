@@ -60,3 +60,44 @@ def test_graphed_resnet20_step_trains():
     losses = [float(step(x, y)) for _ in range(25)]
     assert step.captures == 1
     assert losses[-1] < losses[0] * 0.7, losses
+
+
+@pytest.mark.parametrize("model_name", ["resnet20", "bert_tiny"])
+def test_training_is_bit_identical_across_runs_with_a_fixed_seed(model_name):
+    """Race / determinism check: every reduction in the hand-written kernels has a fixed order (two-stage partial
+    sums, split-K slabs, sorted-run embedding gradients), so two runs from the same seed agree to the bit."""
+    from distributed_tensorflow_amd.comm.backend import Comm
+    from distributed_tensorflow_amd.engine.optimizer import Adam
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.ops import conv
+    from distributed_tensorflow_amd.parallel.mirrored import MirroredStrategy
+
+    dev = torch.device("cuda:0")
+    saved = conv.get_conv1x1_backend(), conv.get_convkxk_backend()
+    conv.set_conv1x1_backend("gemm")          # the vendor library's weight-gradient kernels use atomics
+    conv.set_convkxk_backend("gemm")
+    try:
+        def run():
+            torch.manual_seed(0)
+            if model_name == "resnet20":
+                from distributed_tensorflow_amd.models.resnet import resnet20
+                model, cfg = resnet20(10), TrainConfig(param_dtype=torch.bfloat16, grad_dtype=torch.bfloat16)
+                g = torch.Generator().manual_seed(3)
+                x = torch.randn(64, 32, 32, 3, generator=g).to(dev).bfloat16()
+                y = torch.randint(0, 10, (64,), generator=g).to(dev)
+            else:
+                from distributed_tensorflow_amd.models.bert import bert_tiny, synthetic_mlm_batch
+                model = bert_tiny(64)
+                cfg = TrainConfig(loss="mlm", param_dtype=torch.bfloat16, grad_dtype=torch.bfloat16)
+                x, y = synthetic_mlm_batch(8, 64, 1024, dev, n_pred=10, seed=3)
+            st = MirroredStrategy(model, Comm(0, 1, dev), cfg, optimizer=Adam(1e-3))
+            losses = [float(st.train_step(x, y)) for _ in range(4)]
+            torch.cuda.synchronize()
+            return losses, st.flat.master[: st.flat.used].clone()
+        l1, w1 = run()
+        l2, w2 = run()
+    finally:
+        conv.set_conv1x1_backend(saved[0])
+        conv.set_convkxk_backend(saved[1])
+    assert l1 == l2
+    assert torch.equal(w1, w2)
