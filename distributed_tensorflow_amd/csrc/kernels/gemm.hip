@@ -89,6 +89,9 @@ struct GemmArgs {
   float drop_scale;      // 1 / (1 - p)
   unsigned long long drop_seed;
   const unsigned long long* drop_off;
+  // optional per-column statistics of the bf16 output for a following batch norm: fp32 [2 * tiles_m][2][N],
+  // row 2 * tile_m + wave_row holds sum(c) and sum(c^2) over that wave's 64 output rows
+  float* col_stats;
   ConvGeom cv;
 };
 
@@ -524,12 +527,25 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   __syncthreads();
   unsigned short* C = reinterpret_cast<unsigned short*>(g.C) + c_off;
   const unsigned short* Cin = g.Cin ? g.Cin + c_off : nullptr;
+  // Column statistics for the batch norm that follows (the accumulators are dead by now, so these 16
+  // registers do not raise the kernel's peak): a lane sees 8 of its wave's 64 rows for one 8-column chunk.
+  float cs0[8], cs1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { cs0[e] = 0.f; cs1[e] = 0.f; }
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int id = lane + 64 * p;
     const int row = id >> 3, chunk = id & 7;
     const int m = wm0 + row, n = wn0 + chunk * 8;
     u32x4 v = *reinterpret_cast<const u32x4*>(stage + swz_off(row, chunk));
+    if (g.col_stats && m < g.M) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+        cs0[2 * e] += lo; cs1[2 * e] = fmaf(lo, lo, cs1[2 * e]);
+        cs0[2 * e + 1] += hi; cs1[2 * e + 1] = fmaf(hi, hi, cs1[2 * e + 1]);
+      }
+    }
     if (m < g.M && n < g.N) {
       long long mr = m;
       if (CONV == 2 && g.cv.S == 2) {       // class-ordered GEMM row -> pixel row in memory
@@ -548,6 +564,25 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
         }
       }
       *reinterpret_cast<u32x4*>(C + mr * g.ldc + n) = v;
+    }
+  }
+  if (g.col_stats) {
+    // combine the 8 lanes that hold the same chunk (lane ^ 8, 16, 32): fixed order, no atomics
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        cs0[e] += __shfl_xor(cs0[e], o, 64);
+        cs1[e] += __shfl_xor(cs1[e], o, 64);
+      }
+    }
+    const int n = wn0 + lane * 8;
+    if (lane < 8 && n < g.N) {
+      float* dst = g.col_stats + ((long long)((m0 / BM) * 2 + wm) * 2) * g.N + n;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{cs0[0], cs0[1], cs0[2], cs0[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs0[4], cs0[5], cs0[6], cs0[7]};
+      *reinterpret_cast<f32x4*>(dst + g.N) = f32x4{cs1[0], cs1[1], cs1[2], cs1[3]};
+      *reinterpret_cast<f32x4*>(dst + g.N + 4) = f32x4{cs1[4], cs1[5], cs1[6], cs1[7]};
     }
   }
 }
@@ -624,6 +659,7 @@ struct GemmExtra {
   int drop_pad;
   unsigned long long drop_seed;
   const void* drop_off;              // device pointer to the 64-bit Philox offset of this call
+  void* col_stats;                   // optional fp32 [2 * ceil(M / 128)][2][N]: per-wave-row column sums of the output
 };
 
 // Sums fp32 split-K slabs [splits][M][N] into C (bias, activation, conversion); shared with gemm256.hip.
@@ -653,6 +689,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   g.bias_dtype = bias_dtype; g.act = act; g.out_fp32 = out_fp32;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0; g.drop_off = nullptr;
+  g.col_stats = nullptr;
   int batch = 1, conv = 0;
   g.nb2 = 1; g.sA1 = g.sA2 = g.sB1 = g.sB2 = g.sC1 = g.sC2 = 0;
   ConvGeom& c = g.cv;
@@ -670,6 +707,12 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
       g.drop_seed = ex->drop_seed;
       g.drop_off = (const unsigned long long*)ex->drop_off;
       splits = 1;                                      // the mask is applied in this kernel's epilogue
+    }
+    if (ex->col_stats) {
+      // whole-output statistics: one plane, plain row order, bf16 output written by this kernel's own epilogue
+      if (out_fp32 || batch > 1 || ex->conv > 1 || N % 8) return -10;
+      g.col_stats = (float*)ex->col_stats;
+      splits = 1;
     }
     conv = ex->conv;
     if (conv) {

@@ -294,6 +294,53 @@ DTF_API int dtf_bn_fwd_train(const void* x, const void* res, void* y, const floa
   return (int)hipGetLastError();
 }
 
+// Folds n_rows partial rows ([n_rows][2][C] fp32, e.g. the per-wave-row column statistics a GEMM epilogue wrote)
+// into n_out rows: block (g, chunk) sums rows [g * per, (g + 1) * per) of 256 consecutive floats of the 2 * C wide
+// row, four loads in flight, in a fixed order.
+__global__ __launch_bounds__(kBlock) void bn_fold_partials_kernel(const float* __restrict__ part, int n_rows, int per,
+                                                                  int width, float* __restrict__ out) {
+  const int e = blockIdx.y * kBlock + threadIdx.x;
+  if (e >= width) return;
+  const int r0 = blockIdx.x * per;
+  const int r1 = min(n_rows, r0 + per);
+  const float* q = part + (long long)r0 * width + e;
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4, q += 4LL * width) {
+    a += q[0]; b += q[width]; c += q[2LL * width]; d += q[3LL * width];
+  }
+  for (; r < r1; ++r, q += width) a += q[0];
+  out[(long long)blockIdx.x * width + e] = (a + b) + (c + d);
+}
+
+constexpr int kFoldRows = 128;
+
+// dtf_bn_fwd_train with the batch statistics already reduced to partial rows by the producer of x: col_stats is
+// fp32 [n_rows][2][C] (sum, sum of squares per channel over disjoint row sets that cover all M rows), so x is read
+// once (by the apply pass) instead of twice. workspace: fp32 [kFoldRows * 2 * C] (used when n_rows > kFoldRows).
+DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                                   float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
+                                   float* shift, const float* col_stats, int n_rows, float* workspace, void* mask_out,
+                                   long long M, int C, float eps, float momentum, int relu, hipStream_t stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (C % 8 || !col_stats || n_rows < 1) return -1;
+  const float* part = col_stats;
+  int np = n_rows;
+  if (n_rows > kFoldRows) {
+    const int per = (n_rows + kFoldRows - 1) / kFoldRows;
+    np = (n_rows + per - 1) / per;
+    hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(np, (2 * C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                       col_stats, n_rows, per, 2 * C, workspace);
+    part = workspace;
+  }
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, part, np, gamma,
+                     beta, run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
+                     (unsigned char*)mask_out, M, C, relu);
+  return (int)hipGetLastError();
+}
+
 DTF_API int dtf_bn_fwd_apply(const void* x, const void* res, void* y, const float* scale, const float* shift,
                              long long M, int C, int relu, hipStream_t stream) {
   if (M <= 0 || C <= 0) return 0;

@@ -42,8 +42,9 @@ class Conv(nn.Module):
         nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
         self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
 
-    def forward(self, x):
-        return conv_ops.conv2d(x, self.weight, self.stride, self.padding)
+    def forward(self, x, bn_stats: bool = False):
+        """``bn_stats=True``: ``(y, partial batch-norm statistics of y or None)``, see ``ops.conv.conv2d``."""
+        return conv_ops.conv2d(x, self.weight, self.stride, self.padding, bn_stats)
 
     def keras_weights(self):
         return [np.ascontiguousarray(self.weight.detach().float().cpu().numpy().transpose(2, 3, 1, 0))]
@@ -68,9 +69,10 @@ class BNAct(nn.Module):
         self.register_buffer("running_mean", torch.zeros(c))
         self.register_buffer("running_var", torch.ones(c))
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, partials=None):
         return norm_ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                       self.training, self.momentum, self.eps, self.relu, residual)
+                                       self.training, self.momentum, self.eps, self.relu, residual,
+                                       partials if self.training else None)
 
     def keras_weights(self):
         return [t.detach().float().cpu().numpy() for t in (self.weight, self.bias, self.running_mean, self.running_var)]
@@ -80,6 +82,15 @@ class BNAct(nn.Module):
             for t, a in zip((self.weight, self.bias, self.running_mean, self.running_var), ws[:4]):
                 t.copy_(torch.from_numpy(np.asarray(a)).to(t.dtype))
         return 4
+
+
+def _conv_bn(conv: "Conv", bn: "BNAct", x, residual=None):
+    """``bn(conv(x) (+ residual))``; in training the convolution hands the batch norm the partial statistics it
+    gathered while storing its output, so the norm reads that output once instead of twice."""
+    if bn.training:
+        y, st = conv(x, bn_stats=True)
+        return bn(y, residual=residual, partials=st)
+    return bn(conv(x), residual=residual)
 
 
 class Bottleneck(nn.Module):
@@ -99,11 +110,14 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         # the alias xi carries the identity branch's gradient into conv1's data-gradient epilogue
         c1 = self.conv1
-        y, xi = conv_ops.conv2d_fork(x, c1.weight, c1.stride, c1.padding)
-        idt = xi if self.down is None else self.down_bn(self.down(xi))
-        y = self.bn1(y)
-        y = self.bn2(self.conv2(y))
-        return self.bn3(self.conv3(y), residual=idt)   # relu(bn(conv) + identity) in one fused pass
+        if self.training:
+            y, xi, st = conv_ops.conv2d_fork(x, c1.weight, c1.stride, c1.padding, bn_stats=True)
+        else:
+            (y, xi), st = conv_ops.conv2d_fork(x, c1.weight, c1.stride, c1.padding), None
+        idt = xi if self.down is None else _conv_bn(self.down, self.down_bn, xi)
+        y = self.bn1(y, partials=st)
+        y = _conv_bn(self.conv2, self.bn2, y)
+        return _conv_bn(self.conv3, self.bn3, y, residual=idt)   # relu(bn(conv) + identity) in one fused pass
 
 
 class BasicBlock(nn.Module):
@@ -117,9 +131,9 @@ class BasicBlock(nn.Module):
             self.down_bn = BNAct(cout, relu=False)
 
     def forward(self, x):
-        idt = x if self.down is None else self.down_bn(self.down(x))
-        y = self.bn1(self.conv1(x))
-        return self.bn2(self.conv2(y), residual=idt)
+        idt = x if self.down is None else _conv_bn(self.down, self.down_bn, x)
+        y = _conv_bn(self.conv1, self.bn1, x)
+        return _conv_bn(self.conv2, self.bn2, y, residual=idt)
 
 
 class Classifier(nn.Module):
@@ -164,7 +178,7 @@ class ResNet50(Model):
 
     def forward(self, x, logits: bool = False):
         x = self.prepare_input(x)
-        x = self.stem_bn(self.stem(x))
+        x = _conv_bn(self.stem, self.stem_bn, x)
         x = pool_ops.max_pool2d(x, 3, 2, 1)
         x = self.blocks(x)
         y = self.head(x)
@@ -190,7 +204,7 @@ class ResNet20(Model):
 
     def forward(self, x, logits: bool = False):
         x = self.prepare_input(x)
-        x = self.stem_bn(self.stem(x))
+        x = _conv_bn(self.stem, self.stem_bn, x)
         x = self.blocks(x)
         y = self.head(x)
         return y if logits else torch.softmax(y.float(), dim=-1)

@@ -59,7 +59,9 @@ class _ConvFn(torch.autograd.Function):
     gradient is accumulated onto inside the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding, auto=False):
+    def forward(ctx, x, w, stride, padding, auto=False, stats=None):
+        """``stats`` (optional, filled in place): fp32 ``[gemm.col_stats_rows(M), 2, K]`` partial batch-norm
+        statistics of the output, accumulated in the GEMM's store phase."""
         N, C, H, W = x.shape
         K, _, KH, KW = w.shape
         OH = (H + 2 * padding - KH) // stride + 1
@@ -67,10 +69,10 @@ class _ConvFn(torch.autograd.Function):
         y = torch.empty((N, OH, OW, K), dtype=x.dtype, device=x.device)
         M = N * OH * OW
         if KH == 1 and KW == 1 and stride == 1 and padding == 0:
-            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, C, C, C, K)
+            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, C, C, C, K, col_stats=stats)
         else:
             ex = _gemm.conv_geom(_gemm.CONV_FWD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
-            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, KH * KW * C, C, KH * KW * C, K, extra=ex)
+            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, KH * KW * C, C, KH * KW * C, K, extra=ex, col_stats=stats)
         ctx.save_for_backward(x, w)
         ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, stride, padding)
         ctx.auto = auto
@@ -120,7 +122,7 @@ class _ConvFn(torch.autograd.Function):
                 ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex)
             gw = gw.permute(0, 3, 1, 2)        # [K, C, KH, KW] with channels_last strides
-        return gx, gw, None, None, None
+        return gx, gw, None, None, None, None
 
 
 class _ConvForkFn(_ConvFn):
@@ -130,14 +132,14 @@ class _ConvForkFn(_ConvFn):
     separate add kernel over the largest activations of the network disappears."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding, auto=False):
-        y = _ConvFn.forward(ctx, x, w, stride, padding, auto)
+    def forward(ctx, x, w, stride, padding, auto=False, stats=None):
+        y = _ConvFn.forward(ctx, x, w, stride, padding, auto, stats)
         return y, x.view_as(x)
 
     @staticmethod
     def backward(ctx, gy, g_alias):
         if gy is None:       # the convolution branch was unused
-            return g_alias, None, None, None, None
+            return g_alias, None, None, None, None, None
         return _ConvFn.backward(ctx, gy, g_alias)
 
 
@@ -148,24 +150,56 @@ def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
             and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24))
 
 
-def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
-    """Bias-free convolution of a channels_last activation with an ``[O, I, kh, kw]`` weight."""
+_bn_stats = os.environ.get("DTF_CONV_BN_STATS", "1") != "0"
+
+
+def set_bn_stats(on: bool) -> None:
+    """Switches the hand-over of partial batch-norm statistics from the convolution to the norm (A/B measurements)."""
+    global _bn_stats
+    _bn_stats = bool(on)
+
+
+def _own_path(x, w, stride, backend) -> bool:
+    return (backend != "library" and stride in (1, 2) and _gemm_ok(x, w)
+            and (stride == 1 or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)))
+
+
+def _stats_buffer(x, w, stride, padding):
+    N, _, H, W = x.shape
+    K, _, KH, KW = w.shape
+    M = N * ((H + 2 * padding - KH) // stride + 1) * ((W + 2 * padding - KW) // stride + 1)
+    return torch.empty((_gemm.col_stats_rows(M), 2, K), dtype=torch.float32, device=x.device)
+
+
+def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0, bn_stats: bool = False):
+    """Bias-free convolution of a channels_last activation with an ``[O, I, kh, kw]`` weight.
+    ``bn_stats=True`` returns ``(y, partials)``: ``partials`` are the per-channel sums and sums of squares of
+    ``y`` over disjoint row sets, accumulated while the GEMM stores ``y`` (pass them to
+    ``ops.norm.batch_norm_act(..., partials=)``, which then reads ``y`` once instead of twice), or ``None`` when
+    the convolution did not run on the framework's own kernel."""
     one = w.shape[2] == 1 and w.shape[3] == 1
     backend = _backend if one else _backend_kxk
-    if backend != "library" and stride in (1, 2) and _gemm_ok(x, w) and (stride == 1 or (x.shape[2] % 2 == 0 and
-                                                                                    x.shape[3] % 2 == 0)):
-        return _ConvFn.apply(x, w, stride, padding, backend == "auto")
+    if _own_path(x, w, stride, backend):
+        st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
+        y = _ConvFn.apply(x, w, stride, padding, backend == "auto", st)
+        return (y, st) if bn_stats else y
     if x.dtype != w.dtype:
         x = x.to(w.dtype)
-    return F.conv2d(x, w, None, stride, padding)
+    y = F.conv2d(x, w, None, stride, padding)
+    return (y, None) if bn_stats else y
 
 
-def conv2d_fork(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0):
+def conv2d_fork(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0, bn_stats: bool = False):
     """``(conv2d(x, w), x')`` where ``x'`` aliases ``x``: use ``x'`` for the other consumer of ``x`` (a
-    residual branch) so that the two gradients of ``x`` are summed inside the data-gradient GEMM."""
+    residual branch) so that the two gradients of ``x`` are summed inside the data-gradient GEMM.
+    With ``bn_stats=True`` the result is ``(y, x', partials)`` (see :func:`conv2d`)."""
     one = w.shape[2] == 1 and w.shape[3] == 1
     backend = _backend if one else _backend_kxk
-    if (backend != "library" and stride in (1, 2) and _gemm_ok(x, w) and x.requires_grad and torch.is_grad_enabled()
-            and (stride == 1 or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0))):
-        return _ConvForkFn.apply(x, w, stride, padding, backend == "auto")
+    if _own_path(x, w, stride, backend) and x.requires_grad and torch.is_grad_enabled():
+        st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
+        y, xi = _ConvForkFn.apply(x, w, stride, padding, backend == "auto", st)
+        return (y, xi, st) if bn_stats else (y, xi)
+    if bn_stats:
+        y, st = conv2d(x, w, stride, padding, True)
+        return y, x, st
     return conv2d(x, w, stride, padding), x

@@ -48,7 +48,7 @@ class GemmExtra(ctypes.Structure):
                 ("KW", ctypes.c_int), ("CI", ctypes.c_int), ("CO", ctypes.c_int), ("NB", ctypes.c_int),
                 ("Cin", ctypes.c_void_p),
                 ("drop_p", ctypes.c_float), ("drop_pad", ctypes.c_int), ("drop_seed", ctypes.c_ulonglong),
-                ("drop_off", ctypes.c_void_p)]
+                ("drop_off", ctypes.c_void_p), ("col_stats", ctypes.c_void_p)]
 
 
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 1, 2, 3
@@ -259,12 +259,27 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=N
                    splits, out)
 
 
+def col_stats_rows(M: int) -> int:
+    """Rows of the column-statistics buffer of an ``M``-row product: two 64-row wave tiles per 128-row tile."""
+    return 2 * ((M + 127) // 128)
+
+
 def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int,
              ldb: int, ldc: int, extra: GemmExtra | None = None, bias=None, activation=None, splits=None,
-             add: torch.Tensor | None = None):
+             add: torch.Tensor | None = None, col_stats: torch.Tensor | None = None):
     """Unchecked launch on explicit dimensions and leading dimensions (batched attention products,
     implicit-GEMM convolutions). ``add`` is a bf16 tensor laid out like ``out`` that is added to the
-    result in the epilogue. The caller guarantees 16-byte alignment of every row it addresses."""
+    result in the epilogue. ``col_stats`` (fp32 ``[2 * ceil(M / 128), 2, N]``, see :func:`col_stats_rows`)
+    receives per-wave-row column sums and sums of squares of the bf16 output, the partial statistics of a
+    batch norm that follows. The caller guarantees 16-byte alignment of every row it addresses."""
+    if col_stats is not None:
+        if (col_stats.dtype != torch.float32 or not col_stats.is_contiguous() or out.dtype != torch.bfloat16
+                or tuple(col_stats.shape) != (col_stats_rows(M), 2, N)):
+            raise ValueError("gemm_raw: col_stats must be a contiguous fp32 [col_stats_rows(M), 2, N] tensor")
+        if extra is None:
+            extra = GemmExtra()
+            extra.nb1 = extra.nb2 = 1
+        extra.col_stats = col_stats.data_ptr()
     for t in (A, B, out):
         if t.data_ptr() % 16:
             raise ValueError("gemm_raw: operands must be 16-byte aligned")

@@ -33,7 +33,7 @@ def _fast_path(x: torch.Tensor) -> bool:
 
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, relu, residual):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, relu, residual, partials=None):
         N, C, H, W = x.shape
         M = N * H * W
         dev = x.device
@@ -50,11 +50,24 @@ class _BNActFn(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.relu = 0 if not relu else (3 if residual is not None else 2)
         mask = torch.empty(M * C // 8, dtype=torch.uint8, device=dev) if ctx.relu == 3 else None
-        rc = lib.dtf_bn_fwd_train(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta),
-                                  _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
-                                  _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), _lib.ptr(mask),
-                                  ctypes.c_longlong(M), C, ctypes.c_float(eps), ctypes.c_float(momentum), int(relu),
-                                  _lib.stream_ptr(dev))
+        if partials is not None:
+            # the producer of x already reduced sum(x), sum(x^2) to partial rows: x is read once, by the apply pass
+            if partials.dtype != torch.float32 or partials.dim() != 3 or tuple(partials.shape[1:]) != (2, C) \
+                    or not partials.is_contiguous():
+                raise ValueError("batch_norm_act: partials must be a contiguous fp32 [rows, 2, C] tensor")
+            ws = _scratch(dev, max(nb, 128) * 2 * C)
+            rc = lib.dtf_bn_fwd_train_stats(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma),
+                                            _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]),
+                                            _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
+                                            _lib.ptr(partials), int(partials.shape[0]), _lib.ptr(ws), _lib.ptr(mask),
+                                            ctypes.c_longlong(M), C, ctypes.c_float(eps), ctypes.c_float(momentum),
+                                            int(relu), _lib.stream_ptr(dev))
+        else:
+            rc = lib.dtf_bn_fwd_train(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta),
+                                      _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
+                                      _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), _lib.ptr(mask),
+                                      ctypes.c_longlong(M), C, ctypes.c_float(eps), ctypes.c_float(momentum),
+                                      int(relu), _lib.stream_ptr(dev))
         _lib.check(rc, "bn_fwd_train")
         ctx.save_for_backward(x, mask, gamma, stats)
         return y
@@ -82,14 +95,16 @@ class _BNActFn(torch.autograd.Function):
         _lib.check(rc, "bn_bwd")
         if ctx.has_res and ctx.relu == 0:
             dres = dy
-        return dx, dgb[0], dgb[1], None, None, None, None, None, dres
+        return dx, dgb[0], dgb[1], None, None, None, None, None, dres, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, momentum: float = 0.1,
-                   eps: float = 1e-5, relu: bool = True, residual=None):
+                   eps: float = 1e-5, relu: bool = True, residual=None, partials=None):
+    """``partials`` (training, fast path only): fp32 ``[rows, 2, C]`` partial sums ``sum(x)``, ``sum(x^2)`` over
+    disjoint row sets covering ``x``, as produced by ``ops.conv.conv2d(..., bn_stats=True)``."""
     if _fast_path(x) and gamma.dtype == torch.float32:
         if training:
-            return _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual)
+            return _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual, partials)
         scale = gamma * torch.rsqrt(running_var + eps)
         shift = beta - running_mean * scale
         N, C, H, W = x.shape

@@ -729,3 +729,33 @@ def test_ffn_fork_fused_gelu_epilogues_match_fp32_reference(M):
         assert torch.allclose(a.grad.float(), r.grad, atol=0.03 * float(r.grad.abs().max()) + 1e-3, rtol=5e-2), \
             float((a.grad.float() - r.grad).abs().max())
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(4, 64, 56, 256, 1, 1, 0), (3, 128, 28, 128, 3, 1, 1), (5, 64, 30, 72, 3, 2, 1),
+                                 (2, 256, 14, 1024, 1, 1, 0)])
+def test_conv_hands_batch_norm_its_partial_statistics(cfg):
+    """The GEMM store phase accumulates sum(y), sum(y^2) per channel; the batch norm that consumes them must give
+    the result of the two-pass norm (same values, different summation order)."""
+    from distributed_tensorflow_amd.ops import conv, norm
+    N, C, H, K, k, stride, pad = cfg
+    torch.manual_seed(N * C + K)
+    x = torch.randn(N, C, H, H, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(K, C, k, k, device=DEV) * (1.0 / (C * k * k) ** 0.5)).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    y, st = conv.conv2d(x, w, stride, pad, bn_stats=True)
+    assert st is not None and st.shape[1:] == (2, K)
+    yf = y.float().permute(0, 2, 3, 1).reshape(-1, K)
+    tot = st.sum(0)
+    assert torch.allclose(tot[0], yf.sum(0), rtol=1e-4, atol=1e-2 * float(yf.abs().max()))
+    assert torch.allclose(tot[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
+    gamma, beta = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV)
+    res = torch.randn_like(y)
+    outs = []
+    for partials in (None, st):
+        rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+        o = norm.batch_norm_act(y, gamma, beta, rm, rv, True, 0.1, 1e-5, True, res, partials=partials)
+        outs.append((o.float(), rm, rv))
+    assert torch.allclose(outs[0][0], outs[1][0], atol=2e-2, rtol=2e-2)
+    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-5, rtol=1e-4)
+    assert torch.allclose(outs[0][2], outs[1][2], atol=1e-5, rtol=1e-4)
