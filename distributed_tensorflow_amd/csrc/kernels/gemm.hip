@@ -92,6 +92,15 @@ struct GemmArgs {
   // optional per-column statistics of the bf16 output for a following batch norm: fp32 [2 * tiles_m][2][N],
   // row 2 * tile_m + wave_row holds sum(c) and sum(c^2) over that wave's 64 output rows
   float* col_stats;
+  // stats_mode 1: the output is the gradient dy entering a batch norm whose input was bn_x (laid out like C). The
+  // rows then hold sum dy' and sum dy' * (bn_x - mean), dy' = dy masked by the norm's ReLU: bn_relu 0 none,
+  // 2 sign of fma(bn_x, bn_scale, bn_shift), 3 one bit per element in bn_mask (byte (m * ldc + n) / 8).
+  int stats_mode, bn_relu;
+  const unsigned short* bn_x;
+  const float* bn_mean;
+  const float* bn_scale;
+  const float* bn_shift;
+  const unsigned char* bn_mask;
   ConvGeom cv;
 };
 
@@ -532,13 +541,45 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   float cs0[8], cs1[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { cs0[e] = 0.f; cs1[e] = 0.f; }
+  // per-channel constants of the lane's fixed 8-column chunk (batch-norm backward statistics only)
+  float bmu[8], bsa[8], bsb[8];
+  if (g.col_stats && g.stats_mode == 1) {
+    const int n = wn0 + (lane & 7) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool in = n + e < g.N;
+      bmu[e] = in ? g.bn_mean[n + e] : 0.f;
+      bsa[e] = in && g.bn_relu == 2 ? g.bn_scale[n + e] : 0.f;
+      bsb[e] = in && g.bn_relu == 2 ? g.bn_shift[n + e] : 0.f;
+    }
+  }
+  // ... and the norm's input (and mask bytes), fetched four passes at a time so that their latency is paid twice
+  // per tile rather than per pass (all eight at once would cost the kernel its third resident block)
+  u32x4 bxv[4];
+  unsigned bkeep[4];
+  auto fetch_bn = [&](int p0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int id = lane + 64 * (p0 + q);
+      const int m = wm0 + (id >> 3), n = wn0 + (id & 7) * 8;
+      bxv[q] = u32x4{0u, 0u, 0u, 0u};
+      bkeep[q] = 0xffu;
+      if (m < g.M && n < g.N) {
+        const long long at = c_off + (long long)m * g.ldc + n;
+        bxv[q] = *reinterpret_cast<const u32x4*>(g.bn_x + at);
+        if (g.bn_relu == 3) bkeep[q] = g.bn_mask[at >> 3];
+      }
+    }
+  };
+  const bool bn_grad_stats = g.col_stats && g.stats_mode == 1;
+  if (bn_grad_stats) fetch_bn(0);
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int id = lane + 64 * p;
     const int row = id >> 3, chunk = id & 7;
     const int m = wm0 + row, n = wn0 + chunk * 8;
     u32x4 v = *reinterpret_cast<const u32x4*>(stage + swz_off(row, chunk));
-    if (g.col_stats && m < g.M) {
+    if (g.col_stats && g.stats_mode == 0 && m < g.M) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
@@ -564,7 +605,27 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
         }
       }
       *reinterpret_cast<u32x4*>(C + mr * g.ldc + n) = v;
+      if (bn_grad_stats) {
+        // v is the finished gradient (accumulate input included): mask it like the norm's backward will
+        const u32x4 xv = bxv[p & 3];
+        const unsigned keep = bkeep[p & 3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xl = __uint_as_float(xv[e] << 16), xh = __uint_as_float(xv[e] & 0xffff0000u);
+          float gl = __uint_as_float(v[e] << 16), gh = __uint_as_float(v[e] & 0xffff0000u);
+          if (g.bn_relu == 2) {
+            gl = fmaf(xl, bsa[2 * e], bsb[2 * e]) > 0.f ? gl : 0.f;
+            gh = fmaf(xh, bsa[2 * e + 1], bsb[2 * e + 1]) > 0.f ? gh : 0.f;
+          } else {
+            gl = (keep >> (2 * e)) & 1u ? gl : 0.f;
+            gh = (keep >> (2 * e + 1)) & 1u ? gh : 0.f;
+          }
+          cs0[2 * e] += gl; cs1[2 * e] = fmaf(gl, xl - bmu[2 * e], cs1[2 * e]);
+          cs0[2 * e + 1] += gh; cs1[2 * e + 1] = fmaf(gh, xh - bmu[2 * e + 1], cs1[2 * e + 1]);
+        }
+      }
     }
+    if (p == 3 && bn_grad_stats) fetch_bn(4);
   }
   if (g.col_stats) {
     // combine the 8 lanes that hold the same chunk (lane ^ 8, 16, 32): fixed order, no atomics
@@ -660,6 +721,12 @@ struct GemmExtra {
   unsigned long long drop_seed;
   const void* drop_off;              // device pointer to the 64-bit Philox offset of this call
   void* col_stats;                   // optional fp32 [2 * ceil(M / 128)][2][N]: per-wave-row column sums of the output
+  int stats_mode, bn_relu;           // see GemmArgs: 1 = statistics of a batch norm's incoming gradient
+  const void* bn_x;
+  const void* bn_mean;
+  const void* bn_scale;
+  const void* bn_shift;
+  const void* bn_mask;
 };
 
 // Sums fp32 split-K slabs [splits][M][N] into C (bias, activation, conversion); shared with gemm256.hip.
@@ -689,7 +756,8 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   g.bias_dtype = bias_dtype; g.act = act; g.out_fp32 = out_fp32;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0; g.drop_off = nullptr;
-  g.col_stats = nullptr;
+  g.col_stats = nullptr; g.stats_mode = 0; g.bn_relu = 0;
+  g.bn_x = nullptr; g.bn_mean = g.bn_scale = g.bn_shift = nullptr; g.bn_mask = nullptr;
   int batch = 1, conv = 0;
   g.nb2 = 1; g.sA1 = g.sA2 = g.sB1 = g.sB2 = g.sC1 = g.sC2 = 0;
   ConvGeom& c = g.cv;
@@ -710,9 +778,18 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
     }
     if (ex->col_stats) {
       // whole-output statistics: one plane, plain row order, bf16 output written by this kernel's own epilogue
-      if (out_fp32 || batch > 1 || ex->conv > 1 || N % 8) return -10;
+      if (out_fp32 || batch > 1 || ex->conv == 3 || (ex->conv == 2 && ex->S != 1) || N % 8) return -10;
       g.col_stats = (float*)ex->col_stats;
       splits = 1;
+      if (ex->stats_mode == 1) {
+        if (!ex->bn_x || !ex->bn_mean || (ex->bn_relu == 2 && (!ex->bn_scale || !ex->bn_shift)) ||
+            (ex->bn_relu == 3 && !ex->bn_mask) || (ex->bn_relu != 0 && ex->bn_relu != 2 && ex->bn_relu != 3))
+          return -10;
+        g.stats_mode = 1; g.bn_relu = ex->bn_relu;
+        g.bn_x = (const unsigned short*)ex->bn_x; g.bn_mean = (const float*)ex->bn_mean;
+        g.bn_scale = (const float*)ex->bn_scale; g.bn_shift = (const float*)ex->bn_shift;
+        g.bn_mask = (const unsigned char*)ex->bn_mask;
+      }
     }
     conv = ex->conv;
     if (conv) {

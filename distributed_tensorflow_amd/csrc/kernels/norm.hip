@@ -173,10 +173,12 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_bwd_kernel(const float* __
                                        const float* __restrict__ gamma,
                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cA,
-                                       float* __restrict__ cK, float* __restrict__ c0, long long M, int C) {
+                                       float* __restrict__ cK, float* __restrict__ c0, long long M, int C,
+                                       int s1_centered_only) {
   float s0, s1;
   if (!bn_sum_partials(part, n_part, C, s0, s1)) return;
   const int c = blockIdx.x * kFinCh + (threadIdx.x % kFinCh);
+  if (s1_centered_only) s1 *= invstd[c];     // the partials hold sum dy' * (x - mean): the producer had no invstd
   dbeta[c] = s0; dgamma[c] = s1;
   const float inv_m = 1.f / (float)M;
   const float a = gamma[c] * invstd[c];
@@ -313,11 +315,12 @@ __global__ __launch_bounds__(kBlock) void bn_fold_partials_kernel(const float* _
   out[(long long)blockIdx.x * width + e] = (a + b) + (c + d);
 }
 
-constexpr int kFoldRows = 128;
+constexpr int kFoldRows = 256;            // rows a fold leaves
+constexpr int kFoldAbove = kBnMaxPartials; // the finalize kernels take up to this many rows directly
 
 // dtf_bn_fwd_train with the batch statistics already reduced to partial rows by the producer of x: col_stats is
 // fp32 [n_rows][2][C] (sum, sum of squares per channel over disjoint row sets that cover all M rows), so x is read
-// once (by the apply pass) instead of twice. workspace: fp32 [kFoldRows * 2 * C] (used when n_rows > kFoldRows).
+// once (by the apply pass) instead of twice. workspace: fp32 [kFoldRows * 2 * C] (used when n_rows > kFoldAbove).
 DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                    float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
                                    float* shift, const float* col_stats, int n_rows, float* workspace, void* mask_out,
@@ -326,7 +329,7 @@ DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, cons
   if (C % 8 || !col_stats || n_rows < 1) return -1;
   const float* part = col_stats;
   int np = n_rows;
-  if (n_rows > kFoldRows) {
+  if (n_rows > kFoldAbove) {
     const int per = (n_rows + kFoldRows - 1) / kFoldRows;
     np = (n_rows + per - 1) / per;
     hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(np, (2 * C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
@@ -367,7 +370,34 @@ DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float
                      (const unsigned short*)dy, (const unsigned short*)y, mean, invstd, scale, shift, workspace, M, C,
                      relu);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb, gamma, mean,
-                     invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C);
+                     invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 0);
+  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+                     (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,
+                     coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C, relu);
+  return (int)hipGetLastError();
+}
+
+// dtf_bn_bwd with the reductions over the incoming gradient already done by its producer (the data-gradient GEMM
+// of the following convolution): col_stats is fp32 [n_rows][2][C] holding sum dy' and sum dy' * (x - mean) over
+// disjoint row sets, dy' being the gradient after the ReLU mask. x and dy are then read once (by the apply pass).
+// workspace: fp32 [kFoldRows * 2 * C].
+DTF_API int dtf_bn_bwd_stats(const void* x, const void* dy, const void* y, const float* gamma, const float* mean,
+                             const float* invstd, const float* scale, const float* shift, void* dx, void* dres,
+                             float* dgamma, float* dbeta, float* coef, const float* col_stats, int n_rows,
+                             float* workspace, long long M, int C, int relu, hipStream_t stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (C % 8 || !col_stats || n_rows < 1) return -1;
+  const float* part = col_stats;
+  int np = n_rows;
+  if (n_rows > kFoldAbove) {
+    const int per = (n_rows + kFoldRows - 1) / kFoldRows;
+    np = (n_rows + per - 1) / per;
+    hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(np, (2 * C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                       col_stats, n_rows, per, 2 * C, workspace);
+    part = workspace;
+  }
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, part, np, gamma,
+                     mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 1);
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,
                      coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C, relu);

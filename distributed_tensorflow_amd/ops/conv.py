@@ -59,8 +59,9 @@ class _ConvFn(torch.autograd.Function):
     gradient is accumulated onto inside the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding, auto=False, stats=None):
-        """``stats`` (optional, filled in place): fp32 ``[gemm.col_stats_rows(M), 2, K]`` partial batch-norm
+    def forward(ctx, x, w, stride, padding, auto=False, stats=None, grad_req=None):
+        """``grad_req``: the ``ops.norm.GradStatsRequest`` of the batch norm that produced ``x``, if any.
+        ``stats`` (optional, filled in place): fp32 ``[gemm.col_stats_rows(M), 2, K]`` partial batch-norm
         statistics of the output, accumulated in the GEMM's store phase."""
         N, C, H, W = x.shape
         K, _, KH, KW = w.shape
@@ -76,6 +77,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, stride, padding)
         ctx.auto = auto
+        ctx.grad_req = grad_req
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -106,11 +108,20 @@ class _ConvFn(torch.autograd.Function):
             if (g_alias is not None and g_alias.dtype == gx.dtype and g_alias.shape == x.shape
                     and g_alias.is_contiguous(memory_format=torch.channels_last)):
                 add, g_alias = g_alias.permute(0, 2, 3, 1), None
+            # x came out of a batch norm: reduce that norm's backward sums over gx while gx is stored
+            req, part, bn_grad = ctx.grad_req, None, None
+            if (_bn_grad_stats and req is not None and req.x is not None and stride == 1 and req.x.shape == x.shape
+                    and req.x.dtype == torch.bfloat16 and req.x.is_contiguous(memory_format=torch.channels_last)):
+                part = torch.empty((_gemm.col_stats_rows(N * H * W), 2, C), dtype=torch.float32, device=x.device)
+                bn_grad = (req.x, req.stats, req.mask, req.relu)
             if plain:
-                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, K, K, C, C, add=add)
+                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, K, K, C, C, add=add, col_stats=part, bn_grad=bn_grad)
             else:
                 ex = _gemm.conv_geom(_gemm.CONV_DGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
-                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, KH * KW * K, K, KH * KW * C, C, extra=ex, add=add)
+                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, KH * KW * K, K, KH * KW * C, C, extra=ex, add=add,
+                               col_stats=part, bn_grad=bn_grad)
+            if part is not None:
+                req.partials, req.dy_ptr = part, gx.data_ptr()
             gx = gx.permute(0, 3, 1, 2)
         if g_alias is not None and ctx.needs_input_grad[0]:
             gx = g_alias if gx is None else gx + g_alias
@@ -122,7 +133,7 @@ class _ConvFn(torch.autograd.Function):
                 ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex)
             gw = gw.permute(0, 3, 1, 2)        # [K, C, KH, KW] with channels_last strides
-        return gx, gw, None, None, None, None
+        return gx, gw, None, None, None, None, None
 
 
 class _ConvForkFn(_ConvFn):
@@ -132,14 +143,14 @@ class _ConvForkFn(_ConvFn):
     separate add kernel over the largest activations of the network disappears."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding, auto=False, stats=None):
-        y = _ConvFn.forward(ctx, x, w, stride, padding, auto, stats)
+    def forward(ctx, x, w, stride, padding, auto=False, stats=None, grad_req=None):
+        y = _ConvFn.forward(ctx, x, w, stride, padding, auto, stats, grad_req)
         return y, x.view_as(x)
 
     @staticmethod
     def backward(ctx, gy, g_alias):
         if gy is None:       # the convolution branch was unused
-            return g_alias, None, None, None, None, None
+            return g_alias, None, None, None, None, None, None
         return _ConvFn.backward(ctx, gy, g_alias)
 
 
@@ -153,10 +164,21 @@ def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
 _bn_stats = os.environ.get("DTF_CONV_BN_STATS", "1") != "0"
 
 
-def set_bn_stats(on: bool) -> None:
-    """Switches the hand-over of partial batch-norm statistics from the convolution to the norm (A/B measurements)."""
-    global _bn_stats
+_bn_grad_stats = os.environ.get("DTF_CONV_BN_GRAD_STATS", "1") != "0"
+
+
+def set_bn_stats(on: bool, grad: bool | None = None) -> None:
+    """Switches the hand-over of partial batch-norm statistics between convolution and norm (A/B measurements):
+    ``on`` the forward sums a convolution gathers for the norm after it, ``grad`` (default: same as ``on``) the
+    backward sums its data-gradient GEMM gathers for the norm before it."""
+    global _bn_stats, _bn_grad_stats
     _bn_stats = bool(on)
+    _bn_grad_stats = bool(on if grad is None else grad)
+
+
+def _norm_request(x):
+    from . import norm as _norm
+    return _norm.request_of(x) if (_bn_grad_stats and torch.is_grad_enabled()) else None
 
 
 def _own_path(x, w, stride, backend) -> bool:
@@ -181,7 +203,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0, 
     backend = _backend if one else _backend_kxk
     if _own_path(x, w, stride, backend):
         st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
-        y = _ConvFn.apply(x, w, stride, padding, backend == "auto", st)
+        y = _ConvFn.apply(x, w, stride, padding, backend == "auto", st, _norm_request(x))
         return (y, st) if bn_stats else y
     if x.dtype != w.dtype:
         x = x.to(w.dtype)
@@ -197,7 +219,7 @@ def conv2d_fork(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int 
     backend = _backend if one else _backend_kxk
     if _own_path(x, w, stride, backend) and x.requires_grad and torch.is_grad_enabled():
         st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
-        y, xi = _ConvForkFn.apply(x, w, stride, padding, backend == "auto", st)
+        y, xi = _ConvForkFn.apply(x, w, stride, padding, backend == "auto", st, _norm_request(x))
         return (y, xi, st) if bn_stats else (y, xi)
     if bn_stats:
         y, st = conv2d(x, w, stride, padding, True)

@@ -48,7 +48,10 @@ class GemmExtra(ctypes.Structure):
                 ("KW", ctypes.c_int), ("CI", ctypes.c_int), ("CO", ctypes.c_int), ("NB", ctypes.c_int),
                 ("Cin", ctypes.c_void_p),
                 ("drop_p", ctypes.c_float), ("drop_pad", ctypes.c_int), ("drop_seed", ctypes.c_ulonglong),
-                ("drop_off", ctypes.c_void_p), ("col_stats", ctypes.c_void_p)]
+                ("drop_off", ctypes.c_void_p), ("col_stats", ctypes.c_void_p),
+                ("stats_mode", ctypes.c_int), ("bn_relu", ctypes.c_int), ("bn_x", ctypes.c_void_p),
+                ("bn_mean", ctypes.c_void_p), ("bn_scale", ctypes.c_void_p), ("bn_shift", ctypes.c_void_p),
+                ("bn_mask", ctypes.c_void_p)]
 
 
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 1, 2, 3
@@ -266,7 +269,7 @@ def col_stats_rows(M: int) -> int:
 
 def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int,
              ldb: int, ldc: int, extra: GemmExtra | None = None, bias=None, activation=None, splits=None,
-             add: torch.Tensor | None = None, col_stats: torch.Tensor | None = None):
+             add: torch.Tensor | None = None, col_stats: torch.Tensor | None = None, bn_grad=None):
     """Unchecked launch on explicit dimensions and leading dimensions (batched attention products,
     implicit-GEMM convolutions). ``add`` is a bf16 tensor laid out like ``out`` that is added to the
     result in the epilogue. ``col_stats`` (fp32 ``[2 * ceil(M / 128), 2, N]``, see :func:`col_stats_rows`)
@@ -280,6 +283,17 @@ def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M
             extra = GemmExtra()
             extra.nb1 = extra.nb2 = 1
         extra.col_stats = col_stats.data_ptr()
+        if bn_grad is not None:
+            # the output is the gradient entering a batch norm: bn_grad = (norm input laid out like out,
+            # stats [4, N] = mean, invstd, scale, shift, mask bytes or None, relu code 0 | 2 | 3)
+            bx, bstats, bmask, brelu = bn_grad
+            if bx.dtype != torch.bfloat16 or bx.numel() != M * N or ldc != N or bstats.dtype != torch.float32 \
+                    or tuple(bstats.shape) != (4, N) or (brelu == 3 and bmask is None):
+                raise ValueError("gemm_raw: bn_grad does not match the output")
+            extra.stats_mode, extra.bn_relu = 1, int(brelu)
+            extra.bn_x, extra.bn_mean = bx.data_ptr(), bstats[0].data_ptr()
+            extra.bn_scale, extra.bn_shift = bstats[2].data_ptr(), bstats[3].data_ptr()
+            extra.bn_mask = bmask.data_ptr() if bmask is not None else None
     for t in (A, B, out):
         if t.data_ptr() % 16:
             raise ValueError("gemm_raw: operands must be 16-byte aligned")

@@ -31,9 +31,31 @@ def _fast_path(x: torch.Tensor) -> bool:
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
+class GradStatsRequest:
+    """Hand-over between a batch norm and the convolution that consumes its output. The norm's forward fills in
+    what its backward reductions need (input, statistics, ReLU mask); the convolution's backward, whose
+    data-gradient GEMM produces the very gradient those reductions run over, performs them while it stores that
+    gradient and leaves ``partials`` here together with the address of the gradient they belong to. The norm's
+    backward uses them only if the gradient it receives is that tensor (a single consumer), and otherwise
+    reduces on its own."""
+    __slots__ = ("x", "stats", "mask", "relu", "partials", "dy_ptr")
+
+    def __init__(self):
+        self.x = self.stats = self.mask = self.partials = None
+        self.relu, self.dy_ptr = 0, 0
+
+
+_REQ_ATTR = "_dtf_grad_stats_request"
+
+
+def request_of(t: torch.Tensor):
+    """The :class:`GradStatsRequest` attached to a batch-norm output (None for any other tensor)."""
+    return getattr(t, _REQ_ATTR, None)
+
+
 class _BNActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, relu, residual, partials=None):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, relu, residual, partials=None, request=None):
         N, C, H, W = x.shape
         M = N * H * W
         dev = x.device
@@ -55,7 +77,7 @@ class _BNActFn(torch.autograd.Function):
             if partials.dtype != torch.float32 or partials.dim() != 3 or tuple(partials.shape[1:]) != (2, C) \
                     or not partials.is_contiguous():
                 raise ValueError("batch_norm_act: partials must be a contiguous fp32 [rows, 2, C] tensor")
-            ws = _scratch(dev, max(nb, 128) * 2 * C)
+            ws = _scratch(dev, max(nb, 256) * 2 * C)
             rc = lib.dtf_bn_fwd_train_stats(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma),
                                             _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]),
                                             _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
@@ -70,6 +92,9 @@ class _BNActFn(torch.autograd.Function):
                                       int(relu), _lib.stream_ptr(dev))
         _lib.check(rc, "bn_fwd_train")
         ctx.save_for_backward(x, mask, gamma, stats)
+        ctx.request = request
+        if request is not None:
+            request.x, request.stats, request.mask, request.relu = x, stats, mask, ctx.relu
         return y
 
     @staticmethod
@@ -88,14 +113,27 @@ class _BNActFn(torch.autograd.Function):
         lib = _lib.kernels()
         nb = lib.dtf_bn_num_partials(ctypes.c_longlong(M), C)
         ws = _scratch(dev, nb * 2 * C)
-        rc = lib.dtf_bn_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(stats[0]),
-                            _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(dx), _lib.ptr(dres),
-                            _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(coef), _lib.ptr(ws), ctypes.c_longlong(M), C,
-                            int(ctx.relu), _lib.stream_ptr(dev))
+        req = ctx.request
+        if req is not None and req.partials is not None and req.dy_ptr == dy.data_ptr():
+            # the convolution that consumed the output already reduced this very gradient
+            part = req.partials
+            ws = _scratch(dev, max(nb, 256) * 2 * C)
+            rc = lib.dtf_bn_bwd_stats(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(stats[0]),
+                                      _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(dx),
+                                      _lib.ptr(dres), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(coef),
+                                      _lib.ptr(part), int(part.shape[0]), _lib.ptr(ws), ctypes.c_longlong(M), C,
+                                      int(ctx.relu), _lib.stream_ptr(dev))
+        else:
+            rc = lib.dtf_bn_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(stats[0]),
+                                _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(dx),
+                                _lib.ptr(dres), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(coef), _lib.ptr(ws),
+                                ctypes.c_longlong(M), C, int(ctx.relu), _lib.stream_ptr(dev))
+        if req is not None:
+            req.x = req.stats = req.mask = req.partials = None
         _lib.check(rc, "bn_bwd")
         if ctx.has_res and ctx.relu == 0:
             dres = dy
-        return dx, dgb[0], dgb[1], None, None, None, None, None, dres, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, dres, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, momentum: float = 0.1,
@@ -104,7 +142,12 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, mo
     disjoint row sets covering ``x``, as produced by ``ops.conv.conv2d(..., bn_stats=True)``."""
     if _fast_path(x) and gamma.dtype == torch.float32:
         if training:
-            return _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual, partials)
+            # the request rides on the output tensor: ops.conv picks it up from its input (see GradStatsRequest)
+            req = GradStatsRequest() if (torch.is_grad_enabled() and x.requires_grad) else None
+            y = _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual, partials, req)
+            if req is not None:
+                setattr(y, _REQ_ATTR, req)
+            return y
         scale = gamma * torch.rsqrt(running_var + eps)
         shift = beta - running_mean * scale
         N, C, H, W = x.shape
