@@ -112,6 +112,21 @@ __device__ __forceinline__ void divmod(int x, int d, float rcp, int& q, int& r) 
   else if (r >= d) { ++q; r -= d; }
 }
 
+// v summed over the 8 lanes {lane ^ 8, lane ^ 16, lane ^ 32 and their combinations}, without a trip through LDS:
+// a DPP rotation inside the 16-lane row, then the gfx950 row / half swaps (swapping a value with itself returns
+// {rows 0,0,2,2 | rows 1,1,3,3} and {lower half twice | upper half twice}).
+__device__ __forceinline__ float sum_lanes_8_16_32(float v) {
+  typedef unsigned int u32x2_s __attribute__((ext_vector_type(2)));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+  unsigned u = __float_as_uint(v);
+  const u32x2_s a = __builtin_bit_cast(u32x2_s, __builtin_amdgcn_permlane16_swap(u, u, false, false));
+  const unsigned a0 = a[0], a1 = a[1];
+  u = __float_as_uint(__uint_as_float(a0) + __uint_as_float(a1));
+  const u32x2_s b = __builtin_bit_cast(u32x2_s, __builtin_amdgcn_permlane32_swap(u, u, false, false));
+  const unsigned b0 = b[0], b1 = b[1];
+  return __uint_as_float(b0) + __uint_as_float(b1);
+}
+
 __device__ __forceinline__ int swz_off(int row, int chunk) {
   return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
@@ -631,11 +646,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     // combine the 8 lanes that hold the same chunk (lane ^ 8, 16, 32): fixed order, no atomics
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1) {
-        cs0[e] += __shfl_xor(cs0[e], o, 64);
-        cs1[e] += __shfl_xor(cs1[e], o, 64);
-      }
+      cs0[e] = sum_lanes_8_16_32(cs0[e]);
+      cs1[e] = sum_lanes_8_16_32(cs1[e]);
     }
     const int n = wn0 + lane * 8;
     if (lane < 8 && n < g.N) {
