@@ -73,6 +73,7 @@ struct GemmArgs {
   void* C;               // bf16 or fp32 [M][ldc]; fp32 [splits][batch][M][N] workspace when splits > 1
   const void* bias;      // [N] or null
   const unsigned short* Cin;  // optional bf16 tensor added to the result (same indexing as C)
+  const unsigned char* cin_mask;  // optional: one bit per element of Cin (byte (m * ldc + n) / 8); 0 = add nothing
   long long lda, ldb, ldc;
   int M, N, K;
   int k_per_split;       // multiple of BK
@@ -611,7 +612,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
       }
       if (Cin) {
         // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
-        const u32x4 c = *reinterpret_cast<const u32x4*>(Cin + mr * g.ldc + n);
+        u32x4 c = *reinterpret_cast<const u32x4*>(Cin + mr * g.ldc + n);
+        if (g.cin_mask) {
+          // C_in is a gradient that still has to pass a ReLU: the mask its producer would have applied
+          const unsigned keep = g.cin_mask[(c_off + mr * g.ldc + n) >> 3];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            c[e] &= ((keep >> (2 * e)) & 1u ? 0x0000ffffu : 0u) | ((keep >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float lo = __uint_as_float(v[e] << 16) + __uint_as_float(c[e] << 16);
@@ -739,6 +747,7 @@ struct GemmExtra {
   const void* bn_scale;
   const void* bn_shift;
   const void* bn_mask;
+  const void* cin_mask;              // optional ReLU mask bits applied to Cin before it is added
 };
 
 // Sums fp32 split-K slabs [splits][M][N] into C (bias, activation, conversion); shared with gemm256.hip.
@@ -764,7 +773,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   if (splits < 1) splits = 1;
   GemmArgs g;
   g.A = (const unsigned short*)A; g.B = (const unsigned short*)B;
-  g.bias = bias; g.Cin = nullptr; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.bias = bias; g.Cin = nullptr; g.cin_mask = nullptr; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.bias_dtype = bias_dtype; g.act = act; g.out_fp32 = out_fp32;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0; g.drop_off = nullptr;
@@ -780,6 +789,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
     batch = nb1 * g.nb2;
     g.sA1 = ex->sA1; g.sA2 = ex->sA2; g.sB1 = ex->sB1; g.sB2 = ex->sB2; g.sC1 = ex->sC1; g.sC2 = ex->sC2;
     g.Cin = (const unsigned short*)ex->Cin;
+    g.cin_mask = g.Cin ? (const unsigned char*)ex->cin_mask : nullptr;
     if (ex->drop_p > 0.f) {
       if (!ex->drop_off || ex->drop_p >= 1.f || ex->conv || ex->nb1 > 1 || ex->nb2 > 1) return -8;
       g.drop_thresh = dropout_threshold(ex->drop_p);

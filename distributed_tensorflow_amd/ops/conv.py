@@ -88,6 +88,21 @@ class _ConvFn(torch.autograd.Function):
         N, C, H, W, K, KH, KW, OH, OW, stride, padding = ctx.geom
         if not gy.is_contiguous(memory_format=torch.channels_last):
             gy = gy.contiguous(memory_format=torch.channels_last)
+        # a norm-add-ReLU that took the alias as its residual may have handed over its incoming gradient
+        # unmasked, with the mask to apply (ops.norm.ForkToken)
+        alias_mask = None
+        token = getattr(ctx, "fork_token", None)
+        if token is not None and token.masked_grad is not None:
+            ptr, alias_mask = token.masked_grad
+            token.masked_grad = None
+            if g_alias is None or g_alias.data_ptr() != ptr:
+                raise RuntimeError("conv2d_fork: the alias fed a norm-add-ReLU residual AND another consumer; the "
+                                   "masked gradient hand-over needs the residual to be its only use "
+                                   "(ops.conv.set_bn_stats(False) disables the hand-over)")
+            if not (g_alias.dtype == x.dtype and g_alias.shape == x.shape
+                    and g_alias.is_contiguous(memory_format=torch.channels_last)
+                    and ctx.needs_input_grad[0] and not (ctx.auto and stride != 1)):
+                g_alias, alias_mask = _apply_mask_bits(g_alias, alias_mask), None
         plain = KH == 1 and KW == 1 and stride == 1 and padding == 0
         gx = gw = None
         # per-pass routing of 'auto' (see the module docstring)
@@ -104,10 +119,10 @@ class _ConvFn(torch.autograd.Function):
                 gw, want_w = lgw, False
         if want_x:
             gx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
-            add = None
+            add = add_mask = None
             if (g_alias is not None and g_alias.dtype == gx.dtype and g_alias.shape == x.shape
                     and g_alias.is_contiguous(memory_format=torch.channels_last)):
-                add, g_alias = g_alias.permute(0, 2, 3, 1), None
+                add, g_alias, add_mask = g_alias.permute(0, 2, 3, 1), None, alias_mask
             # x came out of a batch norm: reduce that norm's backward sums over gx while gx is stored
             req, part, bn_grad = ctx.grad_req, None, None
             if (_bn_grad_stats and req is not None and req.x is not None and stride == 1 and req.x.shape == x.shape
@@ -115,11 +130,12 @@ class _ConvFn(torch.autograd.Function):
                 part = torch.empty((_gemm.col_stats_rows(N * H * W), 2, C), dtype=torch.float32, device=x.device)
                 bn_grad = (req.x, req.stats, req.mask, req.relu)
             if plain:
-                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, K, K, C, C, add=add, col_stats=part, bn_grad=bn_grad)
+                _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, K, K, C, C, add=add, col_stats=part, bn_grad=bn_grad,
+                               add_mask=add_mask)
             else:
                 ex = _gemm.conv_geom(_gemm.CONV_DGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, KH * KW * K, K, KH * KW * C, C, extra=ex, add=add,
-                               col_stats=part, bn_grad=bn_grad)
+                               col_stats=part, bn_grad=bn_grad, add_mask=add_mask)
             if part is not None:
                 req.partials, req.dy_ptr = part, gx.data_ptr()
             gx = gx.permute(0, 3, 1, 2)
@@ -143,15 +159,19 @@ class _ConvForkFn(_ConvFn):
     separate add kernel over the largest activations of the network disappears."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding, auto=False, stats=None, grad_req=None):
+    def forward(ctx, x, w, stride, padding, auto=False, stats=None, grad_req=None, token=None):
         y = _ConvFn.forward(ctx, x, w, stride, padding, auto, stats, grad_req)
+        ctx.fork_token = token
         return y, x.view_as(x)
 
     @staticmethod
     def backward(ctx, gy, g_alias):
         if gy is None:       # the convolution branch was unused
-            return g_alias, None, None, None, None, None, None
-        return _ConvFn.backward(ctx, gy, g_alias)
+            tk = ctx.fork_token
+            if tk is not None and tk.masked_grad is not None:
+                g_alias, tk.masked_grad = _apply_mask_bits(g_alias, tk.masked_grad[1]), None
+            return g_alias, None, None, None, None, None, None, None
+        return _ConvFn.backward(ctx, gy, g_alias) + (None,)
 
 
 def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -174,6 +194,16 @@ def set_bn_stats(on: bool, grad: bool | None = None) -> None:
     global _bn_stats, _bn_grad_stats
     _bn_stats = bool(on)
     _bn_grad_stats = bool(on if grad is None else grad)
+
+
+def _apply_mask_bits(g: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """``g`` with the elements whose bit in ``mask`` (one bit per element in memory order) is 0 set to zero --
+    the slow path of the masked gradient hand-over, for gradients that cannot ride the GEMM epilogue."""
+    gm = g.contiguous(memory_format=torch.channels_last) if g.dim() == 4 else g.contiguous()
+    flat = gm.permute(0, 2, 3, 1).reshape(-1, 8) if g.dim() == 4 else gm.reshape(-1, 8)
+    bits = (mask.reshape(-1, 1) >> torch.arange(8, device=mask.device, dtype=torch.uint8)) & 1
+    out = (flat * bits.to(flat.dtype)).reshape(gm.permute(0, 2, 3, 1).shape if g.dim() == 4 else gm.shape)
+    return out.permute(0, 3, 1, 2) if g.dim() == 4 else out
 
 
 def _norm_request(x):
@@ -219,7 +249,11 @@ def conv2d_fork(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int 
     backend = _backend if one else _backend_kxk
     if _own_path(x, w, stride, backend) and x.requires_grad and torch.is_grad_enabled():
         st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
-        y, xi = _ConvForkFn.apply(x, w, stride, padding, backend == "auto", st, _norm_request(x))
+        from . import norm as _norm
+        token = _norm.ForkToken() if (_bn_grad_stats and w.shape[2] == 1 and w.shape[3] == 1 and stride == 1) else None
+        y, xi = _ConvForkFn.apply(x, w, stride, padding, backend == "auto", st, _norm_request(x), token)
+        if token is not None:
+            setattr(xi, _norm._TOKEN_ATTR, token)
         return (y, xi, st) if bn_stats else (y, xi)
     if bn_stats:
         y, st = conv2d(x, w, stride, padding, True)

@@ -51,7 +51,7 @@ class GemmExtra(ctypes.Structure):
                 ("drop_off", ctypes.c_void_p), ("col_stats", ctypes.c_void_p),
                 ("stats_mode", ctypes.c_int), ("bn_relu", ctypes.c_int), ("bn_x", ctypes.c_void_p),
                 ("bn_mean", ctypes.c_void_p), ("bn_scale", ctypes.c_void_p), ("bn_shift", ctypes.c_void_p),
-                ("bn_mask", ctypes.c_void_p)]
+                ("bn_mask", ctypes.c_void_p), ("cin_mask", ctypes.c_void_p)]
 
 
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 1, 2, 3
@@ -269,7 +269,8 @@ def col_stats_rows(M: int) -> int:
 
 def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int,
              ldb: int, ldc: int, extra: GemmExtra | None = None, bias=None, activation=None, splits=None,
-             add: torch.Tensor | None = None, col_stats: torch.Tensor | None = None, bn_grad=None):
+             add: torch.Tensor | None = None, col_stats: torch.Tensor | None = None, bn_grad=None,
+             add_mask: torch.Tensor | None = None):
     """Unchecked launch on explicit dimensions and leading dimensions (batched attention products,
     implicit-GEMM convolutions). ``add`` is a bf16 tensor laid out like ``out`` that is added to the
     result in the epilogue. ``col_stats`` (fp32 ``[2 * ceil(M / 128), 2, N]``, see :func:`col_stats_rows`)
@@ -304,6 +305,10 @@ def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M
             extra = GemmExtra()
             extra.nb1 = extra.nb2 = 1
         extra.Cin = add.data_ptr()
+        if add_mask is not None:      # uint8, one bit per element of ``add``: elements whose bit is 0 are not added
+            if add_mask.dtype != torch.uint8 or add_mask.numel() * 8 != M * N or ldc != N:
+                raise ValueError("gemm_raw: add_mask must hold one bit per element of a dense add= tensor")
+            extra.cin_mask = add_mask.data_ptr()
     if lda % 8 or ldb % 8 or ldc % 8:
         raise ValueError("gemm_raw: leading dimensions must be multiples of 8 elements")
     return _launch(layout, A, B, M, N, K, lda, ldb, bias, activation, out.dtype, splits, out=out, extra=extra, ldc=ldc)

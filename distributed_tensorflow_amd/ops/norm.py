@@ -45,6 +45,19 @@ class GradStatsRequest:
         self.relu, self.dy_ptr = 0, 0
 
 
+class ForkToken:
+    """Marks the alias output of ``ops.conv.conv2d_fork``. When that alias is the residual input of a
+    norm-add-ReLU, the norm's backward does not write the masked gradient of the residual branch: it hands the
+    incoming gradient itself to the branch and leaves the ReLU mask here (``masked_grad`` = address of that
+    gradient, mask bytes); the fork's backward, which accumulates the branch gradient in its data-gradient GEMM
+    epilogue anyway, applies the mask there. One pass over the widest activations of the network is saved."""
+    __slots__ = ("masked_grad",)
+
+    def __init__(self):
+        self.masked_grad = None
+
+
+_TOKEN_ATTR = "_dtf_fork_token"
 _REQ_ATTR = "_dtf_grad_stats_request"
 
 
@@ -71,6 +84,7 @@ class _BNActFn(torch.autograd.Function):
         # without a residual it is recomputed from x and nothing is kept
         ctx.has_res = residual is not None
         ctx.relu = 0 if not relu else (3 if residual is not None else 2)
+        ctx.fork_token = getattr(residual, _TOKEN_ATTR, None) if (residual is not None and relu) else None
         mask = torch.empty(M * C // 8, dtype=torch.uint8, device=dev) if ctx.relu == 3 else None
         if partials is not None:
             # the producer of x already reduced sum(x), sum(x^2) to partial rows: x is read once, by the apply pass
@@ -107,6 +121,11 @@ class _BNActFn(torch.autograd.Function):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         need_dres = ctx.has_res and ctx.relu != 0
+        token = ctx.fork_token
+        if need_dres and token is not None and dy.dtype == torch.bfloat16:
+            need_dres = False             # the residual branch receives dy and the mask (see ForkToken)
+        else:
+            token = None
         dres = torch.empty_like(x) if need_dres else None
         dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
         coef = torch.empty(3, C, dtype=torch.float32, device=dev)
@@ -132,6 +151,9 @@ class _BNActFn(torch.autograd.Function):
             req.x = req.stats = req.mask = req.partials = None
         _lib.check(rc, "bn_bwd")
         if ctx.has_res and ctx.relu == 0:
+            dres = dy
+        if token is not None:
+            token.masked_grad = (dy.data_ptr(), y)       # y holds the mask bytes saved by the forward pass
             dres = dy
         return dx, dgb[0], dgb[1], None, None, None, None, None, dres, None, None
 

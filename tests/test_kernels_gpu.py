@@ -811,3 +811,42 @@ def test_norm_backward_sums_from_the_consuming_convolution(block):
         # against the fully unfused path the forward statistics differ in the last bits, which this deliberately
         # ill-conditioned loss amplifies (both are ~10 % from an fp32 run); a wrong sum would be far outside
         assert rel(grads["both"][n], grads["none"][n]) < 8e-2, (n, rel(grads["both"][n], grads["none"][n]))
+
+
+@pytest.mark.gpu
+def test_masked_residual_gradient_hand_over_and_its_guards():
+    """norm-add-ReLU with a fork alias as residual: the branch gradient travels unmasked plus mask bits and the
+    fork's data-gradient epilogue applies them; a second consumer of the alias must fail loudly."""
+    from distributed_tensorflow_amd.ops import conv, norm
+    torch.manual_seed(21)
+    N, C, H = 4, 64, 16
+    x = torch.randn(N, C, H, H, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, C, 1, 1, device=DEV) * 0.1).bfloat16().contiguous(memory_format=torch.channels_last)
+    gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.2
+
+    def run(hand_over, extra_use=False):
+        conv.set_bn_stats(True, hand_over)
+        xi = x.clone().requires_grad_(True)
+        wi = w.clone().requires_grad_(True)
+        y, alias = conv.conv2d_fork(xi, wi, 1, 0)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        out = norm.batch_norm_act(y, gamma, beta, rm, rv, True, 0.1, 1e-5, True, alias)
+        loss = (out.float() * torch.linspace(0.5, 1.5, out.numel(), device=DEV).reshape(out.shape)).sum()
+        if extra_use:
+            loss = loss + alias.float().sum()
+        loss.backward()
+        return xi.grad.float(), wi.grad.float()
+    try:
+        a, b = run(True), run(False)
+        for p, q in zip(a, b):
+            assert torch.allclose(p, q, atol=0.01 * float(q.abs().max()) + 1e-3, rtol=2e-2)
+        with pytest.raises(RuntimeError, match="only use"):
+            run(True, extra_use=True)
+    finally:
+        conv.set_bn_stats(True)
+    # the slow path: mask bits applied by a torch composition
+    g = torch.randn(N, C, H, H, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    keep = torch.rand(N, H, H, C, device=DEV) > 0.5
+    bits = (keep.reshape(-1, 8).to(torch.uint8) << torch.arange(8, device=DEV, dtype=torch.uint8)).sum(1).to(torch.uint8)
+    out = conv._apply_mask_bits(g, bits)
+    assert torch.equal(out.float(), g.float() * keep.permute(0, 3, 1, 2))
