@@ -84,9 +84,10 @@ def main() -> int:
 
     st.cfg.graph = bool(a.graph and dev.type == "cuda")
     step = st.step_callable()
-    if st.cfg.graph:        # eager priming + capture happen before the counted warm-up steps
-        for _ in range(5):
-            step(x, y)
+    # untimed priming before the counted warm-up steps: the convolution library's one-off algorithm search, RCCL's
+    # communicator set-up and (with --graph) the eager steps and the capture all happen here, whatever --warmup is
+    for _ in range(5 if st.cfg.graph else 2):
+        step(x, y)
     for _ in range(a.warmup):
         step(x, y)
     sync()
