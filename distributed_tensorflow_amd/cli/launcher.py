@@ -149,7 +149,7 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
         dev = _device_for(rank, args.device)
         if dev.type == "cuda":
             torch.cuda.set_device(dev)
-        comm = Comm.init(rank, world, dev, "127.0.0.1", port)
+        comm = Comm.init(rank, world, dev, getattr(args, "master_addr", None) or "127.0.0.1", port)
         metrics = MetricsLogger(args.metrics, rank=rank)
         cfg = _train_config(args, centralized=kind in ("sync", "async"))
         model = model_fn()

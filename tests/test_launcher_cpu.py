@@ -122,3 +122,32 @@ def test_multi_machine_roles(tmp_path):
     assert srv.returncode == 0, sout[-2000:]
     assert all(w.returncode == 0 for w in ws), outs
     assert "Test set accuracy: " in sout
+
+
+def test_standalone_role_entry_points_run_a_job_started_by_hand(tmp_path):
+    """The reference's three per-module ``__main__`` commands (broken there), one process each."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = [sys.executable, "-m", "distributed_tensorflow_amd.cli.standalone"]
+    tail = ["--device", "cpu", "--max-steps", "12", "--port", str(port)]
+    srv = subprocess.Popen(base + ["server", "-n", "2", "-s", "127.0.0.1", "-sm", "sync"] + tail, cwd=ROOT, env=ENV,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    ws = [subprocess.Popen(base + ["worker", "-ps", str(i), "-n", "2", "-b", "32", "-s", "127.0.0.1"] + tail, cwd=ROOT,
+                           env=ENV, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in [srv] + ws]
+    assert all(p.returncode == 0 for p in [srv] + ws), outs
+    assert "Test set accuracy" in outs[0] and "elapsed time" in outs[0]
+    # two mirrored workers, each its own command
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    addrs = f"127.0.0.1:{port},127.0.0.1:{port}"
+    ks = [subprocess.Popen(base + ["keras", "-n", "2", "-b", "32", "-i", str(i), "-w", addrs, "--device", "cpu",
+                                   "--max-steps", "12"], cwd=ROOT, env=ENV, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True) for i in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in ks]
+    assert all(p.returncode == 0 for p in ks), outs
+    assert all("eval:" in o for o in outs)
