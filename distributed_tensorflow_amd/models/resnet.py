@@ -17,12 +17,10 @@ moving_mean, moving_variance``, as ``keras.applications``-style models list them
 """
 from __future__ import annotations
 
-import math
 
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ..api.model import Model
 from ..ops import conv as conv_ops

@@ -13,7 +13,6 @@ from __future__ import annotations
 import ctypes
 
 import torch
-import torch.nn as nn
 
 from . import _lib
 

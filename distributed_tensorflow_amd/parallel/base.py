@@ -13,7 +13,6 @@ between the first step and the last, the quantity the reference prints as
 from __future__ import annotations
 
 import time
-from typing import Iterable
 
 import torch
 import torch.distributed as dist

@@ -19,7 +19,6 @@ links of a GPU). The reference reserves the name and a commented-out
 """
 from __future__ import annotations
 
-import time
 
 import torch
 

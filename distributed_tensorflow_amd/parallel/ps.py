@@ -30,12 +30,10 @@ import threading
 import time
 
 import torch
-import torch.distributed as dist
 
 from ..comm.backend import Comm
 from ..engine.optimizer import FlatOptimizer
-from ..engine.replica import Replica, TrainConfig
-from ..ops import bucket as bops
+from ..engine.replica import TrainConfig
 from ..obs.trace import phase
 from .base import Strategy
 
