@@ -276,18 +276,21 @@ def _strategy_worker(rank, world, port, kinds, q):
                 w = np.concatenate([a.reshape(-1) for a in st.replica.model.get_weights()])
                 out[kind] = {"w": w, "losses": losses}
                 comm.barrier()
-                del st
             except Exception as e:  # pragma: no cover
                 import traceback
                 out[kind] = {"error": f"{e}\n{traceback.format_exc()}"}
                 break               # the ranks are out of step from here on
         q.put((rank, out))
-        comm.barrier()
-        comm.shutdown()
     except Exception as e:  # pragma: no cover
         import traceback
         out["init"] = {"error": f"{e}\n{traceback.format_exc()}"}
         q.put((rank, out))
+        return
+    try:                    # the results are out: a slow peer at tear-down is not a test failure
+        comm.barrier()
+        comm.shutdown()
+    except Exception:  # pragma: no cover
+        pass
 
 
 @pytest.fixture(scope="module")
@@ -300,9 +303,9 @@ def two_rank_results():
         p.start()
     got = {}
     try:
-        for _ in range(world):
+        while len(got) < world:
             r, res = q.get(timeout=170)
-            got[r] = res
+            got.setdefault(r, res)
     finally:
         for p in procs:
             p.join(timeout=20)
