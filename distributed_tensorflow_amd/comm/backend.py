@@ -21,6 +21,21 @@ import torch
 import torch.distributed as dist
 
 
+class _StagedWork:
+    """Completion handle of point-to-point transfers that were staged through host memory: ``wait`` finishes the
+    transfers and copies what was received into the device tensors."""
+
+    def __init__(self, works, copies):
+        self.works, self.copies = works, copies
+
+    def wait(self) -> None:
+        for w in self.works:
+            w.wait()
+        for dst, host in self.copies:
+            dst.copy_(host)
+        self.works, self.copies = [], []
+
+
 class Comm:
     def __init__(self, rank: int = 0, world: int = 1, device: torch.device | str = "cpu", group=None,
                  backend: str | None = None):
@@ -79,8 +94,18 @@ class Comm:
             dist.destroy_process_group()
 
     # ------------------------------------------------------------ collectives
+    def _staged(self, t: torch.Tensor) -> bool:
+        """gloo with device tensors (several ranks sharing one GPU, a test configuration): every transfer goes
+        through host memory here rather than through gloo's own device path, which was seen to stall."""
+        return self.composed and t.is_cuda
+
     def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM, async_op: bool = False):
         if self.world == 1:
+            return None
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
             return None
         return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
 
@@ -92,7 +117,7 @@ class Comm:
             return None
         if self.composed:
             # gloo has no reduce_scatter: reduce the whole buffer, keep the local slice
-            w = dist.all_reduce(inp, group=self.group, async_op=False)
+            w = self.all_reduce(inp)
             n = out.numel()
             if out.data_ptr() != inp[self.rank * n:].data_ptr():
                 out.copy_(inp[self.rank * n:(self.rank + 1) * n])
@@ -125,14 +150,10 @@ class Comm:
             return None
         if self.composed:
             n = inp.numel() // self.world
-            ops = []
-            for r in range(self.world):
-                if r == self.rank:
-                    out[r * n:(r + 1) * n].copy_(inp[r * n:(r + 1) * n])
-                    continue
-                ops.append(dist.P2POp(dist.isend, inp[r * n:(r + 1) * n], self._g(r), group=self.group))
-                ops.append(dist.P2POp(dist.irecv, out[r * n:(r + 1) * n], self._g(r), group=self.group))
-            for w in dist.batch_isend_irecv(ops):
+            out[self.rank * n:(self.rank + 1) * n].copy_(inp[self.rank * n:(self.rank + 1) * n])
+            peers = [r for r in range(self.world) if r != self.rank]
+            for w in self.exchange([(inp[r * n:(r + 1) * n], r) for r in peers],
+                                   [(out[r * n:(r + 1) * n], r) for r in peers]):
                 w.wait()
             return None
         return dist.all_to_all_single(out, inp, group=self.group, async_op=async_op)
@@ -140,10 +161,22 @@ class Comm:
     def broadcast(self, t: torch.Tensor, src: int = 0, async_op: bool = False):
         if self.world == 1:
             return None
+        if self._staged(t):
+            h = t.cpu()
+            dist.broadcast(h, src=self._g(src), group=self.group)
+            if self.rank != src:
+                t.copy_(h)
+            return None
         return dist.broadcast(t, src=self._g(src), group=self.group, async_op=async_op)
 
     def reduce(self, t: torch.Tensor, dst: int = 0, async_op: bool = False):
         if self.world == 1:
+            return None
+        if self._staged(t):
+            h = t.cpu()
+            dist.reduce(h, dst=self._g(dst), group=self.group)
+            if self.rank == dst:
+                t.copy_(h)
             return None
         return dist.reduce(t, dst=self._g(dst), group=self.group, async_op=async_op)
 
@@ -156,9 +189,14 @@ class Comm:
 
     # -------------------------------------------------------------------- p2p
     def send(self, t: torch.Tensor, dst: int) -> None:
-        dist.send(t, self._g(dst), group=self.group)
+        dist.send(t.cpu() if self._staged(t) else t, self._g(dst), group=self.group)
 
     def recv(self, t: torch.Tensor, src: int) -> None:
+        if self._staged(t):
+            h = torch.empty(t.shape, dtype=t.dtype)
+            dist.recv(h, self._g(src), group=self.group)
+            t.copy_(h)
+            return
         dist.recv(t, self._g(src), group=self.group)
 
     def exchange(self, sends: Sequence[tuple[torch.Tensor, int]], recvs: Sequence[tuple[torch.Tensor, int]]):
@@ -166,6 +204,11 @@ class Comm:
         call, so transfers to different peers run concurrently over their own xGMI links)."""
         if not sends and not recvs:
             return []
+        if self.composed and any(t.is_cuda for t, _ in list(sends) + list(recvs)):
+            hosts = [(torch.empty(t.shape, dtype=t.dtype), s, t) for t, s in recvs]
+            ops = [dist.P2POp(dist.isend, t.cpu(), self._g(d), group=self.group) for t, d in sends]
+            ops += [dist.P2POp(dist.irecv, h, self._g(s), group=self.group) for h, s, _ in hosts]
+            return [_StagedWork(dist.batch_isend_irecv(ops), [(t, h) for h, _, t in hosts])]
         ops = [dist.P2POp(dist.isend, t, self._g(d), group=self.group) for t, d in sends]
         ops += [dist.P2POp(dist.irecv, t, self._g(s), group=self.group) for t, s in recvs]
         return dist.batch_isend_irecv(ops)
@@ -173,6 +216,7 @@ class Comm:
     def all_reduce_scalar(self, v: float, op=dist.ReduceOp.SUM) -> float:
         if self.world == 1:
             return v
-        t = torch.tensor([v], dtype=torch.float64 if self.device.type == "cpu" else torch.float32, device=self.device)
+        host = self.device.type == "cpu" or self.composed
+        t = torch.tensor([v], dtype=torch.float64 if host else torch.float32, device="cpu" if host else self.device)
         dist.all_reduce(t, op=op, group=self.group)
         return float(t)

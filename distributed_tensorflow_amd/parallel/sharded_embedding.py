@@ -37,7 +37,7 @@ def _all_to_all_v(comm: Comm, send: torch.Tensor, send_counts: list[int], recv_c
         dist.all_to_all_single(out, send.contiguous(), recv_counts, send_counts, group=comm.group)
         return out
     so = ro = 0
-    ops = []
+    sends, recvs = [], []
     for r in range(comm.world):
         s, c = send[so:so + send_counts[r]], out[ro:ro + recv_counts[r]]
         so += send_counts[r]
@@ -46,12 +46,11 @@ def _all_to_all_v(comm: Comm, send: torch.Tensor, send_counts: list[int], recv_c
             c.copy_(s)
             continue
         if s.numel():
-            ops.append(dist.P2POp(dist.isend, s.contiguous(), comm._g(r), group=comm.group))
+            sends.append((s.contiguous(), r))
         if c.numel():
-            ops.append(dist.P2POp(dist.irecv, c, comm._g(r), group=comm.group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+            recvs.append((c, r))
+    for w in comm.exchange(sends, recvs):
+        w.wait()
     return out
 
 
