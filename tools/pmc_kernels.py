@@ -51,6 +51,26 @@ def main():
     w = torch.randn(128, 128, 3, 3, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
     rep(lambda: C.conv2d(x, w, stride=1, padding=1).sum().backward())
     C.set_convkxk_backend("auto")
+    # ResNet-50 stage-1 bottleneck, training mode: 1x1 / 3x3 convolutions that gather the batch-norm statistics in
+    # their store phase, norm + residual + ReLU, masked residual-gradient hand-over
+    from distributed_tensorflow_amd.models import resnet as R
+    blk = R.Bottleneck(256, 64, 1).to(DEV)
+    for m_ in blk.modules():
+        if isinstance(m_, R.Conv):
+            m_.weight.data = m_.weight.data.to(bf).contiguous(memory_format=torch.channels_last)
+    blk.train()
+    xr = torch.randn(256, 256, 56, 56, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
+    rep(lambda: blk(blk(xr)).sum().backward())
+    del xr, blk
+    # transformer feed-forward block with GELU and its derivative in the GEMM epilogues
+    from distributed_tensorflow_amd.ops import dense as D
+    xf = torch.randn(32768, 768, device=DEV).to(bf).requires_grad_(True)
+    w1 = (torch.randn(3072, 768, device=DEV) * 0.03).to(bf).requires_grad_(True)
+    b1 = torch.zeros(3072, device=DEV).to(bf).requires_grad_(True)
+    w2 = (torch.randn(768, 3072, device=DEV) * 0.03).to(bf).requires_grad_(True)
+    b2 = torch.zeros(768, device=DEV).to(bf).requires_grad_(True)
+    rep(lambda: D.ffn_fork(xf, w1, b1, w2, b2)[0].sum().backward())
+    del xf, w1, w2
     # batch norm + ReLU fwd/bwd on the largest ResNet-50 activation
     xb = torch.randn(256, 256, 56, 56, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
     g = torch.ones(256, device=DEV, requires_grad=True)
