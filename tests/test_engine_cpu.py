@@ -208,3 +208,46 @@ def test_reference_loss_on_clipped_probabilities():
     assert float(exact.max()) > float(clipped.max())
     small = torch.randn(6, 10)
     assert torch.allclose(softmax_cross_entropy(small, y), softmax_cross_entropy(small, y, probs_clip_eps=1e-7), atol=1e-5)
+
+
+def test_conv_norm_hand_over_api_degrades_gracefully_off_the_gpu_path():
+    """The statistics hand-over is a GPU fast path; on CPU the same calls return the documented fall-backs."""
+    import torch
+    from distributed_tensorflow_amd.models import resnet as R
+    from distributed_tensorflow_amd.ops import conv, norm
+    x = torch.randn(2, 8, 6, 6).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(16, 8, 3, 3).contiguous(memory_format=torch.channels_last)
+    y, st = conv.conv2d(x, w, 1, 1, bn_stats=True)
+    assert st is None and y.shape == (2, 16, 6, 6)
+    y2, alias, st2 = conv.conv2d_fork(x.requires_grad_(True), w, 1, 1, bn_stats=True)
+    assert st2 is None and alias is x and torch.equal(y2, y)
+    assert norm.request_of(y) is None
+    # mask bits: bit k of byte j keeps element 8 j + k (channels_last memory order)
+    g = torch.arange(2 * 8 * 2 * 2, dtype=torch.float32).reshape(2, 2, 2, 8).permute(0, 3, 1, 2)
+    bits = torch.tensor([0b00000001, 0b10000000, 0xFF, 0x00, 0x0F, 0xF0, 0xAA, 0x55], dtype=torch.uint8)
+    out = conv._apply_mask_bits(g, bits).permute(0, 2, 3, 1).reshape(8, 8)
+    ref = g.permute(0, 2, 3, 1).reshape(8, 8) * torch.tensor(
+        [[(int(b) >> k) & 1 for k in range(8)] for b in bits], dtype=torch.float32)
+    assert torch.equal(out, ref)
+    # a bottleneck block trains and evaluates through the same code on CPU
+    blk = R.Bottleneck(16, 8, 2)
+    xin = torch.randn(2, 16, 8, 8, requires_grad=True)
+    blk.train()
+    blk(xin).sum().backward()
+    assert xin.grad is not None and all(p.grad is not None for p in blk.parameters())
+    blk.eval()
+    with torch.no_grad():
+        assert blk(xin).shape == (2, 32, 4, 4)
+
+
+def test_standalone_parser_keeps_the_reference_role_flags():
+    from distributed_tensorflow_amd.cli import standalone
+    p = standalone.build_parser()
+    a, extra = p.parse_known_args(["worker", "-ps", "1", "-n", "3", "-b", "64", "-ba", "10.0.0.", "-sa", "h", "-s", "srv",
+                                   "--device", "cpu"])
+    assert (a.role, a.index, a.n_nodes, a.batch_size, a.server_address) == ("worker", 1, 3, 64, "srv")
+    assert extra == ["--device", "cpu"]
+    a, _ = p.parse_known_args(["server", "-n", "2", "-sm", "async"])
+    assert (a.role, a.sync_mode, a.server_address) == ("server", "async", "127.0.0.1")
+    a, _ = p.parse_known_args(["keras", "-n", "2", "-i", "1", "-w", "a:1,b:2"])
+    assert (a.role, a.index, a.batch_size, a.worker_addresses) == ("keras", 1, 100, "a:1,b:2")
