@@ -16,6 +16,7 @@
 // These are the BatchNorm + ReLU ops of the ResNet configurations; the reference model has
 // no normalisation layer (reference initializer.py:12-21).
 #include "dtf_common.h"
+#include <algorithm>
 
 using namespace dtf;
 
@@ -401,5 +402,240 @@ DTF_API int dtf_bn_bwd_stats(const void* x, const void* dy, const void* y, const
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,
                      coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C, relu);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ norm + ReLU + max pool in one pass
+// The ResNet stem ends in batch norm, ReLU and a 3x3 / stride-2 max pool over the widest activation of the network.
+// Fused, the normalised activation is never written: the forward pass normalises each tap while it takes the window
+// maximum, and the backward kernels gather the gradient of an input pixel from the (at most ceil(K/S)^2) windows
+// that chose it -- the pool's gather backward -- while they do the norm's two backward passes. Tap values are rounded
+// to bf16 before they are compared, so maxima and winning taps are those of the unfused kernels.
+struct BnPoolGeom {
+  int N, H, W, C, OH, OW, K, S, P;
+};
+typedef unsigned char bp_u8x8 __attribute__((ext_vector_type(8)));
+
+// All three kernels walk image rows: blockIdx.x picks (n, row) with one scalar division per row, and a thread keeps
+// its 8-channel chunk and its pixel slot inside the row for the whole kernel, so the inner loops contain no integer
+// division. KS = 1 compiles the 3x3 / stride-2 / pad-1 geometry of the ResNet stem with constant bounds; KS = 0
+// takes the geometry from the arguments.
+template <int KS>
+__device__ __forceinline__ void bp_geom(const BnPoolGeom& g, int& K, int& S, int& P) {
+  if (KS == 1) { K = 3; S = 2; P = 1; } else { K = g.K; S = g.S; P = g.P; }
+}
+
+template <int KS>
+__global__ __launch_bounds__(kBlock) void bn_relu_maxpool_fwd_kernel(const unsigned short* __restrict__ x,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     unsigned short* __restrict__ y,
+                                                                     unsigned char* __restrict__ idx, BnPoolGeom g) {
+  int K, S, P;
+  bp_geom<KS>(g, K, S, P);
+  const int c8 = g.C >> 3;
+  const int tc = threadIdx.x % c8, slot = threadIdx.x / c8, slots = kBlock / c8;
+  const int c = tc << 3;
+  float sa[8], sb[8];
+  ld8f(scale + c, sa); ld8f(shift + c, sb);
+  const int rows = g.N * g.OH;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / g.OH, oh = row - n * g.OH;
+    for (int ow = slot; ow < g.OW; ow += slots) {
+      float best[8];
+      unsigned char arg[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; arg[k] = 0; }
+#pragma unroll 3
+      for (int kh = 0; kh < K; ++kh) {
+        const int ih = oh * S - P + kh;
+        if (ih < 0 || ih >= g.H) continue;
+#pragma unroll 3
+        for (int kw = 0; kw < K; ++kw) {
+          const int iw = ow * S - P + kw;
+          if (iw < 0 || iw >= g.W) continue;
+          float v[8];
+          ld8bf(x + (((long long)n * g.H + ih) * g.W + iw) * g.C + c, v);
+          const unsigned char tap = (unsigned char)(kh * K + kw);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float f = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(v[k], sa[k], sb[k]), 0.f)));
+            if (f > best[k] || (f != f && best[k] == best[k])) { best[k] = f; arg[k] = tap; }   // first maximum wins
+          }
+        }
+      }
+      bp_u8x8 a;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] = arg[k];
+      const long long o = ((long long)row * g.OW + ow) * g.C + c;
+      st8bf(y + o, best);
+      *reinterpret_cast<bp_u8x8*>(idx + o) = a;
+    }
+  }
+}
+
+// gradient of input pixel (n, ih, iw), channels c..c+7, of the max pool: sum over the windows that chose it
+template <int KS>
+__device__ __forceinline__ void pool_gather_grad(const unsigned short* __restrict__ gy, const unsigned char* __restrict__ idx,
+                                                 const BnPoolGeom& g, int n, int ih, int iw, int c, float (&acc)[8]) {
+  int K, S, P;
+  bp_geom<KS>(g, K, S, P);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  const int oh_hi = min(g.OH - 1, (ih + P) / S);
+  const int ow_hi = min(g.OW - 1, (iw + P) / S);
+  const int oh_lo = max(0, (ih + P - K + S) / S);      // ceil((ih + P - K + 1) / S) where it is non-negative
+  const int ow_lo = max(0, (iw + P - K + S) / S);
+  for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+    const int kh = ih - (oh * S - P);
+    if (kh < 0 || kh >= K) continue;
+    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+      const int kw = iw - (ow * S - P);
+      if (kw < 0 || kw >= K) continue;
+      const long long o = (((long long)n * g.OH + oh) * g.OW + ow) * g.C + c;
+      const bp_u8x8 a = *reinterpret_cast<const bp_u8x8*>(idx + o);
+      float v[8];
+      ld8bf(gy + o, v);
+      const unsigned char tap = (unsigned char)(kh * K + kw);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += a[k] == tap ? v[k] : 0.f;
+    }
+  }
+}
+
+// pass 1 of the backward: per-block partial sum dy', sum dy' * xhat with dy' = pool gradient masked by the ReLU
+// (partial layout of bn_partial_kernel<1>: part[block][2][C]; C <= 2048 and C / 8 divides the block)
+template <int KS>
+__global__ __launch_bounds__(kBlock) void bn_pool_partial_bwd_kernel(const unsigned short* __restrict__ x,
+                                                                     const unsigned short* __restrict__ gy,
+                                                                     const unsigned char* __restrict__ idx,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     float* __restrict__ part, BnPoolGeom g) {
+  __shared__ float red[2][kBlock][8];
+  const int C = g.C, c8 = C >> 3;
+  const int tc = threadIdx.x % c8, slot = threadIdx.x / c8, slots = kBlock / c8;
+  const int c0 = tc * 8;
+  float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float mu[8], is[8], sa[8], sb[8];
+  ld8f(mean + c0, mu); ld8f(invstd + c0, is); ld8f(scale + c0, sa); ld8f(shift + c0, sb);
+  const int rows = g.N * g.H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / g.H, ih = row - n * g.H;
+    for (int iw = slot; iw < g.W; iw += slots) {
+      float v[8], d[8];
+      ld8bf(x + ((long long)row * g.W + iw) * C + c0, v);
+      pool_gather_grad<KS>(gy, idx, g, n, ih, iw, c0, d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float dk = fmaf(v[k], sa[k], sb[k]) > 0.f ? d[k] : 0.f;
+        s0[k] += dk;
+        s1[k] = fmaf(dk, (v[k] - mu[k]) * is[k], s1[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][threadIdx.x][k] = s0[k]; red[1][threadIdx.x][k] = s1[k]; }
+  __syncthreads();
+  if (slot == 0) {
+    for (int r = 1; r < slots; ++r) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s0[k] += red[0][r * c8 + tc][k]; s1[k] += red[1][r * c8 + tc][k]; }
+    }
+    float* p0 = part + ((long long)blockIdx.x * 2) * C + c0;
+    float* p1 = p0 + C;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { p0[k] = s0[k]; p1[k] = s1[k]; }
+  }
+}
+
+// pass 2: dx = A * dy' + K * x + C0
+template <int KS>
+__global__ __launch_bounds__(kBlock) void bn_pool_apply_bwd_kernel(const unsigned short* __restrict__ x,
+                                                                   const unsigned short* __restrict__ gy,
+                                                                   const unsigned char* __restrict__ idx,
+                                                                   const float* __restrict__ cA, const float* __restrict__ cK,
+                                                                   const float* __restrict__ c0, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift,
+                                                                   unsigned short* __restrict__ dx, BnPoolGeom g) {
+  const int c8 = g.C >> 3;
+  const int tc = threadIdx.x % c8, slot = threadIdx.x / c8, slots = kBlock / c8;
+  const int c = tc << 3;
+  float a[8], kk[8], z[8], sa[8], sb[8];
+  ld8f(cA + c, a); ld8f(cK + c, kk); ld8f(c0 + c, z); ld8f(scale + c, sa); ld8f(shift + c, sb);
+  const int rows = g.N * g.H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / g.H, ih = row - n * g.H;
+    for (int iw = slot; iw < g.W; iw += slots) {
+      const long long o = ((long long)row * g.W + iw) * g.C + c;
+      float v[8], d[8];
+      ld8bf(x + o, v);
+      pool_gather_grad<KS>(gy, idx, g, n, ih, iw, c, d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float dk = fmaf(v[k], sa[k], sb[k]) > 0.f ? d[k] : 0.f;
+        v[k] = fmaf(a[k], dk, fmaf(kk[k], v[k], z[k]));
+      }
+      st8bf(dx + o, v);
+    }
+  }
+}
+
+static bool bn_pool_geom_ok(const BnPoolGeom& g) {
+  return g.N > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.C % 8 == 0 && g.C <= 2048 && kBlock % (g.C / 8) == 0 && g.K >= 1 &&
+         g.K <= 15 && g.S >= 1 && g.P >= 0 && g.P < g.K && g.OH == (g.H + 2 * g.P - g.K) / g.S + 1 &&
+         g.OW == (g.W + 2 * g.P - g.K) / g.S + 1;
+}
+
+// y [N,OH,OW,C] = maxpool(relu(bn(x))), idx = winning taps (kh * K + kw); statistics as dtf_bn_fwd_train.
+// workspace: fp32 [dtf_bn_num_partials(N*H*W, C) * 2 * C]. Returns -1 for an unsupported geometry.
+DTF_API int dtf_bn_relu_maxpool_fwd(const void* x, void* y, void* idx, const float* gamma, const float* beta,
+                                    float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
+                                    float* shift, float* workspace, int N, int H, int W, int C, int OH, int OW, int K,
+                                    int S, int P, float eps, float momentum, hipStream_t stream) {
+  const BnPoolGeom g = {N, H, W, C, OH, OW, K, S, P};
+  if (!bn_pool_geom_ok(g)) return -1;
+  const long long M = (long long)N * H * W;
+  const int nb = bn_partials_for(M, C);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nb, 1), dim3(kBlock), 0, stream, (const unsigned short*)x, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb,
+                     gamma, beta, run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
+  const int grid = (int)std::min<long long>((long long)N * OH, kMaxBlocks * 4);
+  if (K == 3 && S == 2 && P == 1)
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, stream, (const unsigned short*)x, scale,
+                       shift, (unsigned short*)y, (unsigned char*)idx, g);
+  else
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<0>, dim3(grid), dim3(kBlock), 0, stream, (const unsigned short*)x, scale,
+                       shift, (unsigned short*)y, (unsigned char*)idx, g);
+  return (int)hipGetLastError();
+}
+
+// dx [N,H,W,C], dgamma, dbeta from gy [N,OH,OW,C]; coef: fp32 [3 * C] scratch; workspace as in the forward.
+DTF_API int dtf_bn_relu_maxpool_bwd(const void* x, const void* gy, const void* idx, const float* gamma, const float* mean,
+                                    const float* invstd, const float* scale, const float* shift, void* dx, float* dgamma,
+                                    float* dbeta, float* coef, float* workspace, int N, int H, int W, int C, int OH,
+                                    int OW, int K, int S, int P, hipStream_t stream) {
+  const BnPoolGeom g = {N, H, W, C, OH, OW, K, S, P};
+  if (!bn_pool_geom_ok(g)) return -1;
+  const long long M = (long long)N * H * W;
+  // one partial row per block of the row-walking reduction; never more than the workspace of the forward holds
+  const int nb = (int)std::min<long long>(bn_partials_for(M, C), (long long)N * H);
+  const int grid = (int)std::min<long long>((long long)N * H, kMaxBlocks * 4);
+  const bool stem = K == 3 && S == 2 && P == 1;
+#define BP_LAUNCH(KS)                                                                                                 \
+  do {                                                                                                                \
+    hipLaunchKernelGGL(bn_pool_partial_bwd_kernel<KS>, dim3(nb), dim3(kBlock), 0, stream, (const unsigned short*)x,   \
+                       (const unsigned short*)gy, (const unsigned char*)idx, mean, invstd, scale, shift, workspace, g); \
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace,   \
+                       nb, gamma, mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 0);                 \
+    hipLaunchKernelGGL(bn_pool_apply_bwd_kernel<KS>, dim3(grid), dim3(kBlock), 0, stream, (const unsigned short*)x,   \
+                       (const unsigned short*)gy, (const unsigned char*)idx, coef, coef + C, coef + 2 * C, scale,     \
+                       shift, (unsigned short*)dx, g);                                                                \
+  } while (0)
+  if (stem) BP_LAUNCH(1); else BP_LAUNCH(0);
+#undef BP_LAUNCH
   return (int)hipGetLastError();
 }

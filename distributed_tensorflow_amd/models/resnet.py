@@ -26,7 +26,6 @@ from ..api.model import Model
 from ..ops import conv as conv_ops
 from ..ops import dense as dense_ops
 from ..ops import norm as norm_ops
-from ..ops import pool as pool_ops
 
 
 class Conv(nn.Module):
@@ -176,8 +175,9 @@ class ResNet50(Model):
 
     def forward(self, x, logits: bool = False):
         x = self.prepare_input(x)
-        x = _conv_bn(self.stem, self.stem_bn, x)
-        x = pool_ops.max_pool2d(x, 3, 2, 1)
+        bn = self.stem_bn            # norm + ReLU + max pool in one pass over the widest activation
+        x = norm_ops.batch_norm_relu_max_pool(self.stem(x), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                              bn.training, bn.momentum, bn.eps, 3, 2, 1)
         x = self.blocks(x)
         y = self.head(x)
         return y if logits else torch.softmax(y.float(), dim=-1)

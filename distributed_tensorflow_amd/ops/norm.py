@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from . import _lib
 
 _ws: dict = {}
+_pool_fused = __import__("os").environ.get("DTF_BN_POOL_FUSED", "1") != "0"
 
 
 def _scratch(device, numel: int) -> torch.Tensor:
@@ -187,3 +188,62 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, mo
     if residual is not None:
         y = y + residual
     return F.relu(y) if relu else y
+
+
+class _BNReluPoolFn(torch.autograd.Function):
+    """``max_pool(relu(bn(x)))`` without materialising the normalised activation (``csrc/kernels/norm.hip``)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, k, s, p):
+        N, C, H, W = x.shape
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        dev = x.device
+        y = torch.empty((N, OH, OW, C), dtype=x.dtype, device=dev)
+        idx = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=dev)
+        stats = torch.empty(4, C, dtype=torch.float32, device=dev)
+        lib = _lib.kernels()
+        nb = lib.dtf_bn_num_partials(ctypes.c_longlong(N * H * W), C)
+        ws = _scratch(dev, nb * 2 * C)
+        rc = lib.dtf_bn_relu_maxpool_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(idx), _lib.ptr(gamma), _lib.ptr(beta),
+                                         _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
+                                         _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), N, H, W, C, OH, OW, k, s,
+                                         p, ctypes.c_float(eps), ctypes.c_float(momentum), _lib.stream_ptr(dev))
+        _lib.check(rc, "bn_relu_maxpool_fwd")
+        ctx.save_for_backward(x, idx, gamma, stats)
+        ctx.geom = (N, C, H, W, OH, OW, k, s, p)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, idx, gamma, stats = ctx.saved_tensors
+        N, C, H, W, OH, OW, k, s, p = ctx.geom
+        dev = x.device
+        if not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
+        coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+        lib = _lib.kernels()
+        nb = lib.dtf_bn_num_partials(ctypes.c_longlong(N * H * W), C)
+        ws = _scratch(dev, nb * 2 * C)
+        rc = lib.dtf_bn_relu_maxpool_bwd(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(idx), _lib.ptr(gamma), _lib.ptr(stats[0]),
+                                         _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(dx),
+                                         _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(coef), _lib.ptr(ws), N, H, W, C, OH,
+                                         OW, k, s, p, _lib.stream_ptr(dev))
+        _lib.check(rc, "bn_relu_maxpool_bwd")
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
+
+
+def batch_norm_relu_max_pool(x, gamma, beta, running_mean, running_var, training: bool, momentum: float = 0.1,
+                             eps: float = 1e-5, kernel_size: int = 3, stride: int = 2, padding: int = 1):
+    """``max_pool2d(relu(batch_norm(x)))`` -- the end of the ResNet stem. In training on the bf16 GPU path the
+    normalised activation (the widest tensor of the network) is never written: the pool normalises its taps on the
+    fly and the norm's backward passes gather the pool's gradient (``DTF_BN_POOL_FUSED=0`` switches this off)."""
+    C = x.shape[1]
+    if (training and _pool_fused and _fast_path(x) and gamma.dtype == torch.float32 and C <= 2048 and 256 % (C // 8) == 0
+            and padding < kernel_size):
+        return _BNReluPoolFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, kernel_size, stride,
+                                   padding)
+    from . import pool as _pool
+    y = batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, True, None)
+    return _pool.max_pool2d(y, kernel_size, stride, padding)

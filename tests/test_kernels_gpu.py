@@ -850,3 +850,31 @@ def test_masked_residual_gradient_hand_over_and_its_guards():
     bits = (keep.reshape(-1, 8).to(torch.uint8) << torch.arange(8, device=DEV, dtype=torch.uint8)).sum(1).to(torch.uint8)
     out = conv._apply_mask_bits(g, bits)
     assert torch.equal(out.float(), g.float() * keep.permute(0, 3, 1, 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(4, 64, 56, 3, 2, 1), (3, 16, 17, 3, 2, 1), (2, 32, 12, 2, 2, 0)])
+def test_norm_relu_max_pool_in_one_pass_matches_the_separate_kernels(cfg):
+    from distributed_tensorflow_amd.ops import norm, pool
+    N, C, H, k, s, p = cfg
+    torch.manual_seed(N + C + H)
+    x = torch.randn(N, C, H, H, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    gamma = (torch.rand(C, device=DEV) + 0.5) * torch.where(torch.arange(C, device=DEV) % 5 == 0, -1.0, 1.0)
+    beta = torch.randn(C, device=DEV) * 0.3
+    res = {}
+    for fused in (True, False):
+        xi, gi, bi = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        if fused:
+            y = norm.batch_norm_relu_max_pool(xi, gi, bi, rm, rv, True, 0.1, 1e-5, k, s, p)
+            assert type(y.grad_fn).__name__ == "_BNReluPoolFnBackward" or y.grad_fn.next_functions
+        else:
+            y = pool.max_pool2d(norm.batch_norm_act(xi, gi, bi, rm, rv, True, 0.1, 1e-5, True, None), k, s, p)
+        w = torch.linspace(0.5, 1.5, y.numel(), device=DEV).reshape(y.shape)
+        (y.float() * w).sum().backward()
+        res[fused] = (y.detach().float(), xi.grad.float(), gi.grad, bi.grad, rm, rv)
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0])                       # taps are compared after bf16 rounding, as unfused
+    assert torch.allclose(a[1], b[1], atol=0.02 * float(b[1].abs().max()) + 1e-4, rtol=2e-2)
+    for i in (2, 3, 4, 5):
+        assert torch.allclose(a[i], b[i], atol=1e-3 * float(b[i].abs().max()) + 1e-5, rtol=1e-3), i
