@@ -583,6 +583,169 @@ __global__ __launch_bounds__(kBlock) void bn_pool_apply_bwd_kernel(const unsigne
   }
 }
 
+// ---- 3x3 / stride 2 / pad 1 backward on 2x2 input patches -------------------------------------------------------------
+// The patch of input pixels (2m..2m+1, 2j..2j+1) lies in exactly the four windows (m..m+1, j..j+1), so a thread that
+// owns a patch loads each window's gradient and tap once (instead of once per covered pixel) and no lane diverges:
+//   pixel (2m  , 2j  ): window (m  , j  ) tap 4
+//   pixel (2m  , 2j+1): window (m  , j  ) tap 5, window (m  , j+1) tap 3
+//   pixel (2m+1, 2j  ): window (m  , j  ) tap 7, window (m+1, j  ) tap 1
+//   pixel (2m+1, 2j+1): window (m  , j  ) tap 8, window (m  , j+1) tap 6, window (m+1, j) tap 2, window (m+1, j+1) tap 0
+// The patch stays packed as loaded (bf16 pairs, four taps per word) and is unpacked one channel at a time, which
+// keeps the kernels near 100 registers; unpacked to fp32 up front they needed over 200 and ran two waves per SIMD.
+typedef unsigned bp_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bp_u32x2 __attribute__((ext_vector_type(2)));
+
+struct BpPatch {
+  bp_u32x4 x[2][2];     // input pixels (zero where outside the image)
+  bp_u32x4 g[2][2];     // gradients of the four windows (zero where outside the pooled image)
+  bp_u32x2 t[2][2];     // winning taps of the four windows (0xff where outside)
+  bool in[2][2];
+};
+
+__device__ __forceinline__ float bp_bf(const bp_u32x4& v, int k) {
+  const unsigned w = v[k >> 1];
+  return __builtin_bit_cast(float, (k & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+__device__ __forceinline__ unsigned bp_tap(const bp_u32x2& v, int k) {
+  const unsigned w = v[k >> 2];
+  return (w >> (8 * (k & 3))) & 0xffu;
+}
+
+__device__ __forceinline__ void bp_load_patch(const unsigned short* __restrict__ x, const unsigned short* __restrict__ gy,
+                                              const unsigned char* __restrict__ idx, const BnPoolGeom& g, int n, int m,
+                                              int j, int c, BpPatch& p) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oh = m + a, ow = j + b;
+      p.g[a][b] = bp_u32x4{0u, 0u, 0u, 0u};
+      p.t[a][b] = bp_u32x2{0xffffffffu, 0xffffffffu};
+      if (oh < g.OH && ow < g.OW) {
+        const long long o = (((long long)n * g.OH + oh) * g.OW + ow) * g.C + c;
+        p.t[a][b] = *reinterpret_cast<const bp_u32x2*>(idx + o);
+        p.g[a][b] = *reinterpret_cast<const bp_u32x4*>(gy + o);
+      }
+      const int ih = 2 * m + a, iw = 2 * j + b;
+      p.in[a][b] = ih < g.H && iw < g.W;
+      p.x[a][b] = bp_u32x4{0u, 0u, 0u, 0u};
+      if (p.in[a][b]) p.x[a][b] = *reinterpret_cast<const bp_u32x4*>(x + (((long long)n * g.H + ih) * g.W + iw) * g.C + c);
+    }
+}
+
+// pool gradient of channel k of the four patch pixels, before the ReLU mask
+__device__ __forceinline__ void bp_grads(const BpPatch& p, int k, float (&d)[2][2]) {
+  const unsigned t00 = bp_tap(p.t[0][0], k), t01 = bp_tap(p.t[0][1], k), t10 = bp_tap(p.t[1][0], k),
+                 t11 = bp_tap(p.t[1][1], k);
+  const float g00 = bp_bf(p.g[0][0], k), g01 = bp_bf(p.g[0][1], k), g10 = bp_bf(p.g[1][0], k), g11 = bp_bf(p.g[1][1], k);
+  d[0][0] = t00 == 4 ? g00 : 0.f;
+  d[0][1] = (t00 == 5 ? g00 : 0.f) + (t01 == 3 ? g01 : 0.f);
+  d[1][0] = (t00 == 7 ? g00 : 0.f) + (t10 == 1 ? g10 : 0.f);
+  d[1][1] = ((t00 == 8 ? g00 : 0.f) + (t01 == 6 ? g01 : 0.f)) + ((t10 == 2 ? g10 : 0.f) + (t11 == 0 ? g11 : 0.f));
+}
+
+__global__ __launch_bounds__(kBlock, 4) void bn_pool322_partial_bwd_kernel(const unsigned short* __restrict__ x,
+                                                                        const unsigned short* __restrict__ gy,
+                                                                        const unsigned char* __restrict__ idx,
+                                                                        const float* __restrict__ mean,
+                                                                        const float* __restrict__ invstd,
+                                                                        const float* __restrict__ scale,
+                                                                        const float* __restrict__ shift,
+                                                                        float* __restrict__ part, BnPoolGeom g) {
+  __shared__ float red[2][kBlock][8];
+  const int C = g.C, c8 = C >> 3;
+  const int tc = threadIdx.x % c8, slot = threadIdx.x / c8, slots = kBlock / c8;
+  const int c0 = tc * 8;
+  float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float mu[8], sa[8], sb[8];
+  ld8f(mean + c0, mu); ld8f(scale + c0, sa); ld8f(shift + c0, sb);
+  const int PH = (g.H + 1) >> 1, PW = (g.W + 1) >> 1;
+  const int rows = g.N * PH;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / PH, m = row - n * PH;
+    for (int j = slot; j < PW; j += slots) {
+      BpPatch p;
+      bp_load_patch(x, gy, idx, g, n, m, j, c0, p);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float d[2][2];
+        bp_grads(p, k, d);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const float v = bp_bf(p.x[a][b], k);
+            const float dk = fmaf(v, sa[k], sb[k]) > 0.f ? d[a][b] : 0.f;   // d is zero outside the image
+            s0[k] += dk;
+            s1[k] = fmaf(dk, v - mu[k], s1[k]);              // times invstd once, below
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][threadIdx.x][k] = s0[k]; red[1][threadIdx.x][k] = s1[k]; }
+  __syncthreads();
+  if (slot == 0) {
+    for (int r = 1; r < slots; ++r) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s0[k] += red[0][r * c8 + tc][k]; s1[k] += red[1][r * c8 + tc][k]; }
+    }
+    float is[8];
+    ld8f(invstd + c0, is);
+    float* p0 = part + ((long long)blockIdx.x * 2) * C + c0;
+    float* p1 = p0 + C;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { p0[k] = s0[k]; p1[k] = s1[k] * is[k]; }
+  }
+}
+
+__global__ __launch_bounds__(kBlock, 4) void bn_pool322_apply_bwd_kernel(const unsigned short* __restrict__ x,
+                                                                      const unsigned short* __restrict__ gy,
+                                                                      const unsigned char* __restrict__ idx,
+                                                                      const float* __restrict__ cA, const float* __restrict__ cK,
+                                                                      const float* __restrict__ c0, const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift,
+                                                                      unsigned short* __restrict__ dx, BnPoolGeom g) {
+  const int c8 = g.C >> 3;
+  const int tc = threadIdx.x % c8, slot = threadIdx.x / c8, slots = kBlock / c8;
+  const int c = tc << 3;
+  float a8[8], kk[8], z[8], sa[8], sb[8];
+  ld8f(cA + c, a8); ld8f(cK + c, kk); ld8f(c0 + c, z); ld8f(scale + c, sa); ld8f(shift + c, sb);
+  const int PH = (g.H + 1) >> 1, PW = (g.W + 1) >> 1;
+  const int rows = g.N * PH;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / PH, m = row - n * PH;
+    for (int j = slot; j < PW; j += slots) {
+      BpPatch p;
+      bp_load_patch(x, gy, idx, g, n, m, j, c, p);
+      bp_u32x4 o[2][2];
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        float d0[2][2], d1[2][2];
+        bp_grads(p, k, d0);
+        bp_grads(p, k + 1, d1);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const float v0 = bp_bf(p.x[a][b], k), v1 = bp_bf(p.x[a][b], k + 1);
+            const float e0 = fmaf(v0, sa[k], sb[k]) > 0.f ? d0[a][b] : 0.f;
+            const float e1 = fmaf(v1, sa[k + 1], sb[k + 1]) > 0.f ? d1[a][b] : 0.f;
+            const float r0 = fmaf(a8[k], e0, fmaf(kk[k], v0, z[k]));
+            const float r1 = fmaf(a8[k + 1], e1, fmaf(kk[k + 1], v1, z[k + 1]));
+            o[a][b][k >> 1] = (unsigned)f32_to_bf16(r0) | ((unsigned)f32_to_bf16(r1) << 16);
+          }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (p.in[a][b])
+            *reinterpret_cast<bp_u32x4*>(dx + (((long long)n * g.H + 2 * m + a) * g.W + 2 * j + b) * g.C + c) = o[a][b];
+    }
+  }
+}
+
 static bool bn_pool_geom_ok(const BnPoolGeom& g) {
   return g.N > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.C % 8 == 0 && g.C <= 2048 && kBlock % (g.C / 8) == 0 && g.K >= 1 &&
          g.K <= 15 && g.S >= 1 && g.P >= 0 && g.P < g.K && g.OH == (g.H + 2 * g.P - g.K) / g.S + 1 &&
@@ -621,21 +784,26 @@ DTF_API int dtf_bn_relu_maxpool_bwd(const void* x, const void* gy, const void* i
   const BnPoolGeom g = {N, H, W, C, OH, OW, K, S, P};
   if (!bn_pool_geom_ok(g)) return -1;
   const long long M = (long long)N * H * W;
-  // one partial row per block of the row-walking reduction; never more than the workspace of the forward holds
-  const int nb = (int)std::min<long long>(bn_partials_for(M, C), (long long)N * H);
-  const int grid = (int)std::min<long long>((long long)N * H, kMaxBlocks * 4);
   const bool stem = K == 3 && S == 2 && P == 1;
-#define BP_LAUNCH(KS)                                                                                                 \
-  do {                                                                                                                \
-    hipLaunchKernelGGL(bn_pool_partial_bwd_kernel<KS>, dim3(nb), dim3(kBlock), 0, stream, (const unsigned short*)x,   \
-                       (const unsigned short*)gy, (const unsigned char*)idx, mean, invstd, scale, shift, workspace, g); \
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace,   \
-                       nb, gamma, mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 0);                 \
-    hipLaunchKernelGGL(bn_pool_apply_bwd_kernel<KS>, dim3(grid), dim3(kBlock), 0, stream, (const unsigned short*)x,   \
-                       (const unsigned short*)gy, (const unsigned char*)idx, coef, coef + C, coef + 2 * C, scale,     \
-                       shift, (unsigned short*)dx, g);                                                                \
-  } while (0)
-  if (stem) BP_LAUNCH(1); else BP_LAUNCH(0);
-#undef BP_LAUNCH
+  // one partial row per block of the row-walking reduction; never more than the workspace of the forward holds
+  const long long rows = stem ? (long long)N * ((H + 1) / 2) : (long long)N * H;
+  const int nb = (int)std::min<long long>(bn_partials_for(M, C), rows);
+  const int grid = (int)std::min<long long>(rows, kMaxBlocks * 4);
+  const unsigned short *xp = (const unsigned short*)x, *gp = (const unsigned short*)gy;
+  const unsigned char* ip = (const unsigned char*)idx;
+  if (stem)
+    hipLaunchKernelGGL(bn_pool322_partial_bwd_kernel, dim3(nb), dim3(kBlock), 0, stream, xp, gp, ip, mean, invstd, scale,
+                       shift, workspace, g);
+  else
+    hipLaunchKernelGGL(bn_pool_partial_bwd_kernel<0>, dim3(nb), dim3(kBlock), 0, stream, xp, gp, ip, mean, invstd, scale,
+                       shift, workspace, g);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb,
+                     gamma, mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 0);
+  if (stem)
+    hipLaunchKernelGGL(bn_pool322_apply_bwd_kernel, dim3(grid), dim3(kBlock), 0, stream, xp, gp, ip, coef, coef + C,
+                       coef + 2 * C, scale, shift, (unsigned short*)dx, g);
+  else
+    hipLaunchKernelGGL(bn_pool_apply_bwd_kernel<0>, dim3(grid), dim3(kBlock), 0, stream, xp, gp, ip, coef, coef + C,
+                       coef + 2 * C, scale, shift, (unsigned short*)dx, g);
   return (int)hipGetLastError();
 }
