@@ -75,7 +75,7 @@ def main() -> int:
         conv.set_conv1x1_backend(a.conv1x1)
     if a.convkxk:
         conv.set_convkxk_backend(a.convkxk)
-    comm = Comm.from_env(dev) if world > 1 else Comm(0, 1, dev)
+    comm = Comm.from_env(dev, timeout_s=1200.0) if world > 1 else Comm(0, 1, dev)   # the first step holds a one-off algorithm search
     st = bench_lib.make_resnet50_strategy(comm, bucket_mb=a.bucket_mb)
     x, y = bench_lib.synthetic_imagenet_batch(a.batch, dev, size=a.image, seed=rank)
 
