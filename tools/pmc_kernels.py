@@ -78,6 +78,13 @@ def main():
     rm, rv = torch.zeros(256, device=DEV), torch.ones(256, device=DEV)
     rep(lambda: N.batch_norm_act(xb, g, b, rm, rv, True, 0.1, 1e-5, relu=True).sum().backward())
     del xb
+    # ResNet stem: batch norm + ReLU + 3x3 / 2 max pool in one forward pass, backward on 2x2 input patches
+    xs_ = torch.randn(256, 64, 112, 112, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
+    gs = torch.ones(64, device=DEV, requires_grad=True)
+    bs = torch.zeros(64, device=DEV, requires_grad=True)
+    rms, rvs = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    rep(lambda: N.batch_norm_relu_max_pool(xs_, gs, bs, rms, rvs, True, 0.1, 1e-5, 3, 2, 1).sum().backward())
+    del xs_
     # layer norm
     xl = torch.randn(32768, 768, device=DEV).to(bf).requires_grad_(True)
     gl = torch.ones(768, device=DEV, requires_grad=True)
