@@ -161,6 +161,16 @@ __device__ __forceinline__ void dgrad_pixel(const ConvGeom& c, int m, int& n, in
   }
 }
 
+// Operand loads go through a buffer descriptor: a 32-bit byte offset per lane instead of a 64-bit address, and a lane
+// whose element lies outside the operand (tile edge, padding of a convolution) passes an offset beyond the
+// descriptor's range and receives zeros from the hardware's range check -- no zero-initialised registers and no
+// divergent branch around the load. Operands are below 4 GiB (checked on the host).
+typedef unsigned buf_u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rs, bool ok, unsigned elem_off) {
+  const unsigned off = ok ? elem_off * 2u : 0xffffffffu;
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Operand stagers. Each thread owns 4 x 16-byte chunks of a tile. Per-row geometry that does not
 // depend on the k-tile is computed once in init() and kept in registers.
@@ -204,6 +214,9 @@ struct Stager {
   __device__ __forceinline__ void load(const GemmArgs& g, const unsigned short* __restrict__ X, long long ld, int rows,
                                        int row0, int k0, int kend, int tap) {
     const ConvGeom& c = g.cv;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, (int)0xffffffffu, 0x00020000);
+    const unsigned uld = (unsigned)ld;
     if (T == 0) {
       const int k = k0 + ((threadIdx.x & 7) << 3);
       const bool kok = k < kend;
@@ -211,9 +224,7 @@ struct Stager {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = row0 + ((threadIdx.x + kThreads * i) >> 3);
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (row < rows && kok) v = *reinterpret_cast<const u32x4*>(X + (long long)row * ld + k);
-          r[i] = v;
+          r[i] = buf_load16(rs, row < rows && kok, (unsigned)row * uld + (unsigned)k);
         }
       } else if (GATHER == 1) {             // k = (kh, kw, ci)
         int t, ci, kh, kw;
@@ -222,10 +233,8 @@ struct Stager {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int ih = ca[i] + kh, iw = cb[i] + kw;
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (rowok[i] && kok && ih >= 0 && ih < c.H && iw >= 0 && iw < c.W)
-            v = *reinterpret_cast<const u32x4*>(X + (long long)(base[i] + kh * c.W + kw) * c.CI + ci);
-          r[i] = v;
+          const bool ok = rowok[i] && kok && ih >= 0 && ih < c.H && iw >= 0 && iw < c.W;
+          r[i] = buf_load16(rs, ok, (unsigned)(base[i] + kh * c.W + kw) * (unsigned)c.CI + (unsigned)ci);
         }
       } else {                              // GATHER 2: k = (kh, kw, co), source pixel ((ih+P-kh)/S, (iw+P-kw)/S)
         int t, co, kh, kw;
@@ -236,10 +245,8 @@ struct Stager {
         for (int i = 0; i < 4; ++i) {
           const int th = ca[i] - kh, tw = cb[i] - kw;
           const int oh = th >> sh, ow = tw >> sh;
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (rowok[i] && kok && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && oh < c.OH && ow < c.OW)
-            v = *reinterpret_cast<const u32x4*>(X + (long long)(base[i] + oh * c.OW + ow) * c.CO + co);
-          r[i] = v;
+          const bool ok = rowok[i] && kok && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && oh < c.OH && ow < c.OW;
+          r[i] = buf_load16(rs, ok, (unsigned)(base[i] + oh * c.OW + ow) * (unsigned)c.CO + (unsigned)co);
         }
       }
     } else {
@@ -258,19 +265,16 @@ struct Stager {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = kf + i;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (rok && k < kend) {
-          if (GATHER == 0) {
-            v = *reinterpret_cast<const u32x4*>(X + (long long)k * ld + row);
-          } else if (GATHER == 4) {         // weights for dgrad: k = (tap, co) -> w[co][tap][ci = row]
-            v = *reinterpret_cast<const u32x4*>(X + (long long)co * ld + t * c.CI + row);
-          } else {                          // GATHER 3: k = output pixel, tap fixed: x[(n, oh*S+kh-P, ow*S+kw-P)][row]
-            const int ih = oh * c.S + tkh - c.P, iw = ow * c.S + tkw - c.P;
-            if (ih >= 0 && ih < c.H && iw >= 0 && iw < c.W)
-              v = *reinterpret_cast<const u32x4*>(X + (long long)((n * c.H + ih) * c.W + iw) * c.CI + row);
-          }
+        const bool ok = rok && k < kend;
+        if (GATHER == 0) {
+          r[i] = buf_load16(rs, ok, (unsigned)k * uld + (unsigned)row);
+        } else if (GATHER == 4) {           // weights for dgrad: k = (tap, co) -> w[co][tap][ci = row]
+          r[i] = buf_load16(rs, ok, (unsigned)co * uld + (unsigned)(t * c.CI + row));
+        } else {                            // GATHER 3: k = output pixel, tap fixed: x[(n, oh*S+kh-P, ow*S+kw-P)][row]
+          const int ih = oh * c.S + tkh - c.P, iw = ow * c.S + tkw - c.P;
+          r[i] = buf_load16(rs, ok && ih >= 0 && ih < c.H && iw >= 0 && iw < c.W,
+                            (unsigned)((n * c.H + ih) * c.W + iw) * (unsigned)c.CI + (unsigned)row);
         }
-        r[i] = v;
         if (GATHER == 4) { if (++co == c.CO) { co = 0; ++t; } }
         if (GATHER == 3) { if (++ow == c.OW) { ow = 0; if (++oh == c.OH) { oh = 0; ++n; } } }
       }
@@ -826,6 +830,15 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   c.r_ohw = 1.f / (float)(c.OH * c.OW); c.r_ow = 1.f / (float)c.OW; c.r_hw = 1.f / (float)(c.H * c.W);
   c.r_w = 1.f / (float)c.W; c.r_ci = 1.f / (float)c.CI; c.r_co = 1.f / (float)c.CO; c.r_kw = 1.f / (float)c.KW;
   if (g.Cin && out_fp32) return -6;
+  {
+    // operands are addressed with 32-bit byte offsets: each must span less than 4 GiB
+    const long long lim = 1ll << 31;   // elements
+    const long long a_el = conv == 1 ? (long long)c.NB * c.H * c.W * c.CI
+                         : conv == 2 ? (long long)c.NB * c.OH * c.OW * c.CO
+                                     : (long long)(layout == 2 ? K : M) * lda;
+    const long long b_el = conv == 3 ? (long long)c.NB * c.H * c.W * c.CI : (long long)(layout == 0 ? N : K) * ldb;
+    if (a_el >= lim || b_el >= lim) return -11;
+  }
   if (g.Cin || (batch > 1 && conv != 3)) splits = 1;   // slabs carry neither C_in nor strided batches
   if (conv == 2 && c.S == 2) splits = 1;               // nor the class-ordered row map of a strided dgrad
   int kps = ((K + splits - 1) / splits + BK - 1) / BK * BK;
