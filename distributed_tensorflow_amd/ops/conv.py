@@ -178,7 +178,9 @@ def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.shape[1] % 8 == 0
             and w.shape[0] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)
             and w.is_contiguous(memory_format=torch.channels_last)
-            and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24))
+            and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)
+            # operands are addressed with 32-bit byte offsets (buffer descriptors): below 2^31 elements each
+            and x.shape[0] * x.shape[2] * x.shape[3] * max(x.shape[1], w.shape[0]) < (1 << 31))
 
 
 _bn_stats = os.environ.get("DTF_CONV_BN_STATS", "1") != "0"

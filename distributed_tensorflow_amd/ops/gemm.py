@@ -35,7 +35,9 @@ def supported(x: torch.Tensor, w: torch.Tensor) -> bool:
     K = x.shape[-1]
     N = w.shape[0]
     return (x.is_cuda and K % 8 == 0 and N % 8 == 0 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
-            and w.is_contiguous() and x.numel() > 0)
+            and w.is_contiguous() and x.numel() > 0
+            # operands are addressed with 32-bit byte offsets (buffer descriptors): below 2^31 elements each
+            and x.numel() < (1 << 31) and w.numel() < (1 << 31) and (x.numel() // K) * N < (1 << 31))
 
 
 class GemmExtra(ctypes.Structure):
