@@ -251,3 +251,19 @@ def test_standalone_parser_keeps_the_reference_role_flags():
     assert (a.role, a.sync_mode, a.server_address) == ("server", "async", "127.0.0.1")
     a, _ = p.parse_known_args(["keras", "-n", "2", "-i", "1", "-w", "a:1,b:2"])
     assert (a.role, a.index, a.batch_size, a.worker_addresses) == ("keras", 1, 100, "a:1,b:2")
+
+
+def test_package_import_keeps_the_conv_library_reference_kernels_out_of_its_search(monkeypatch):
+    """Importing the package must switch the vendor convolution library's reference solvers off by default (they
+    cost over a minute of the first large-batch step) and must leave a user's own setting alone."""
+    import importlib
+    import os
+    import distributed_tensorflow_amd as pkg
+    names = ["MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD",
+             "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW"]
+    for n in names:
+        monkeypatch.delenv(n, raising=False)
+    monkeypatch.setenv(names[0], "1")
+    importlib.reload(pkg)
+    assert os.environ[names[0]] == "1"
+    assert os.environ[names[1]] == "0" and os.environ[names[2]] == "0"
