@@ -182,7 +182,7 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rs, bool ok, 
 template <int T, int GATHER>   // GATHER: 0 plain, 1 conv forward x, 2 conv dgrad dy, 3 conv wgrad x, 4 conv dgrad w
 struct Stager {
   u32x4 r[4];
-  int base[4];       // pixel index base (GATHER 1, 2)
+  int base[4];       // element offset of the row's first tap (GATHER 1, 2; see init)
   int ca[4], cb[4];  // ih0 / iw0 (GATHER 1) or ih+P / iw+P (GATHER 2)
   bool rowok[4];
   int tkh, tkw;      // filter tap of this launch plane (GATHER 3)
@@ -201,11 +201,13 @@ struct Stager {
           divmod(m, c.OH * c.OW, c.r_ohw, n, rem);
           divmod(rem, c.OW, c.r_ow, a, b);
           ca[i] = a * c.S - c.P; cb[i] = b * c.S - c.P;
-          base[i] = (n * c.H + ca[i]) * c.W + cb[i];
+          base[i] = ((n * c.H + ca[i]) * c.W + cb[i]) * c.CI;    // element offset of tap (0, 0); may be negative
         } else {                            // m = input pixel, see dgrad_pixel()
           dgrad_pixel(c, m, n, a, b);
           ca[i] = a + c.P; cb[i] = b + c.P;
-          base[i] = n * c.OH * c.OW;
+          // stride 1: the source pixel is linear in the tap, so the row part of its offset is fixed here;
+          // stride 2: only the image's offset is
+          base[i] = c.S == 1 ? ((n * c.OH + ca[i]) * c.OW + cb[i]) * c.CO : n * c.OH * c.OW * c.CO;
         }
       }
     }
@@ -230,23 +232,33 @@ struct Stager {
         int t, ci, kh, kw;
         divmod(kok ? k : 0, c.CI, c.r_ci, t, ci);
         divmod(t, c.KW, c.r_kw, kh, kw);
+        const int tapo = (kh * c.W + kw) * c.CI + ci;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int ih = ca[i] + kh, iw = cb[i] + kw;
-          const bool ok = rowok[i] && kok && ih >= 0 && ih < c.H && iw >= 0 && iw < c.W;
-          r[i] = buf_load16(rs, ok, (unsigned)(base[i] + kh * c.W + kw) * (unsigned)c.CI + (unsigned)ci);
+          const bool ok = rowok[i] && kok && (unsigned)ih < (unsigned)c.H && (unsigned)iw < (unsigned)c.W;
+          r[i] = buf_load16(rs, ok, (unsigned)(base[i] + tapo));
         }
       } else {                              // GATHER 2: k = (kh, kw, co), source pixel ((ih+P-kh)/S, (iw+P-kw)/S)
         int t, co, kh, kw;
         divmod(kok ? k : 0, c.CO, c.r_co, t, co);
         divmod(t, c.KW, c.r_kw, kh, kw);
-        const int sm = c.S - 1, sh = c.S >> 1;   // S is 1 or 2
+        if (c.S == 1) {
+          const int tapo = co - (kh * c.OW + kw) * c.CO;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int th = ca[i] - kh, tw = cb[i] - kw;
-          const int oh = th >> sh, ow = tw >> sh;
-          const bool ok = rowok[i] && kok && th >= 0 && tw >= 0 && !(th & sm) && !(tw & sm) && oh < c.OH && ow < c.OW;
-          r[i] = buf_load16(rs, ok, (unsigned)(base[i] + oh * c.OW + ow) * (unsigned)c.CO + (unsigned)co);
+          for (int i = 0; i < 4; ++i) {
+            const int th = ca[i] - kh, tw = cb[i] - kw;
+            const bool ok = rowok[i] && kok && (unsigned)th < (unsigned)c.OH && (unsigned)tw < (unsigned)c.OW;
+            r[i] = buf_load16(rs, ok, (unsigned)(base[i] + tapo));
+          }
+        } else {                                 // S == 2
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int th = ca[i] - kh, tw = cb[i] - kw;
+            const int oh = th >> 1, ow = tw >> 1;
+            const bool ok = rowok[i] && kok && th >= 0 && tw >= 0 && !((th | tw) & 1) && oh < c.OH && ow < c.OW;
+            r[i] = buf_load16(rs, ok, (unsigned)(base[i] + (oh * c.OW + ow) * c.CO + co));
+          }
         }
       }
     } else {
