@@ -284,8 +284,8 @@ struct Stager {
           r[i] = buf_load16(rs, ok, (unsigned)co * uld + (unsigned)(t * c.CI + row));
         } else {                            // GATHER 3: k = output pixel, tap fixed: x[(n, oh*S+kh-P, ow*S+kw-P)][row]
           const int ih = oh * c.S + tkh - c.P, iw = ow * c.S + tkw - c.P;
-          r[i] = buf_load16(rs, ok && ih >= 0 && ih < c.H && iw >= 0 && iw < c.W,
-                            (unsigned)((n * c.H + ih) * c.W + iw) * (unsigned)c.CI + (unsigned)row);
+          r[i] = buf_load16(rs, ok && (unsigned)ih < (unsigned)c.H && (unsigned)iw < (unsigned)c.W,
+                            (unsigned)(((n * c.H + ih) * c.W + iw) * c.CI + row));
         }
         if (GATHER == 4) { if (++co == c.CO) { co = 0; ++t; } }
         if (GATHER == 3) { if (++ow == c.OW) { ow = 0; if (++oh == c.OH) { oh = 0; ++n; } } }
