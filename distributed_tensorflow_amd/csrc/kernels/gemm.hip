@@ -777,7 +777,7 @@ DTF_API int dtf_splitk_reduce(const float* W, void* C, const void* bias, int bia
 }
 
 static int g_stages = 0;                 // 0 = automatic
-constexpr int kSingleStageTiles = 32;
+constexpr int kSingleStageTiles = 1 << 20;   // in effect always: one buffer also measured faster on the long weight-gradient loops
 
 // 0 = choose per launch, 1 = one LDS buffer, 2 = two LDS buffers (measurement hook).
 DTF_API void dtf_gemm_set_stages(int stages) { g_stages = stages; }
