@@ -34,7 +34,7 @@ def main():
     ap.parse_args()
     cfgs = [
         # name, measured 1-GPU ms/step, per-GPU batch, backward share, gradient bytes, last bucket bytes, buckets
-        ("ResNet-50 bf16, batch 1024/GPU (bench.py default, 16 MB buckets)", 93.6, 1024, 0.66, 25.6e6 * 2, 8e6, 4),
+        ("ResNet-50 bf16, batch 1024/GPU (bench.py default, 16 MB buckets)", 91.4, 1024, 0.66, 25.6e6 * 2, 8e6, 4),
         ("BERT-base MLM bf16, 64 x 512 tokens/GPU (16 MB buckets)", 32.3, 64, 0.64, 110e6 * 2, 8e6, 14),
     ]
     print("PROJECTED weak scaling on one 8 x MI355X node (model, NOT a measurement; see tools/project_scaling.py)")
