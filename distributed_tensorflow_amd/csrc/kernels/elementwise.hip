@@ -216,3 +216,41 @@ DTF_API int dtf_col_sum_bf16(const void* g, float* out, int M, int N, long long 
     hipLaunchKernelGGL(col_sum_finish_kernel, dim3((N + 31) / 32), dim3(kBlock), 0, stream, workspace, out, gy, N);
   return (int)hipGetLastError();
 }
+
+// Channel padding of an NHWC bf16 image: out[p][0..Cp) = in[p][0..C) followed by zeros (Cp = 4 or a multiple of 8,
+// C < Cp). A first-layer convolution (1, 3 or 4 input channels) is fed through this so that every pixel (Cp = 8) or
+// every pixel pair (Cp = 4) is one aligned 16-byte operand chunk of the implicit-GEMM kernel. A thread writes one
+// 16-byte chunk; its (at most 8) source elements are neighbours in memory, so the scalar loads coalesce.
+__global__ __launch_bounds__(kBlock) void pad_channels_kernel(const unsigned short* __restrict__ in,
+                                                              unsigned short* __restrict__ out, long long n_chunks,
+                                                              int C, int Cp) {
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n_chunks; i += (long long)gridDim.x * kBlock) {
+    u16x8 v;
+    if (Cp == 4) {                     // two pixels per chunk
+      const unsigned short* s = in + i * 2 * C;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int px = e >> 2, c = e & 3;
+        v[e] = c < C ? s[px * C + c] : (unsigned short)0;
+      }
+    } else {                           // Cp / 8 chunks per pixel
+      const int per = Cp >> 3;
+      const long long px = i / per;
+      const int c0 = (int)(i - px * per) << 3;
+      const unsigned short* s = in + px * C;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? s[c0 + e] : (unsigned short)0;
+    }
+    *reinterpret_cast<u16x8*>(out + i * 8) = v;
+  }
+}
+
+// in: bf16 [n_pix][C]; out: bf16 [n_pix][Cp], 16-byte aligned. Cp = 4 needs an even pixel count.
+DTF_API int dtf_pad_channels_bf16(const void* in, void* out, long long n_pix, int C, int Cp, hipStream_t stream) {
+  if (n_pix <= 0) return 0;
+  if (C < 1 || C >= Cp || !(Cp == 4 || Cp % 8 == 0) || (Cp == 4 && (n_pix & 1))) return -1;
+  const long long n_chunks = n_pix * Cp / 8;
+  hipLaunchKernelGGL(pad_channels_kernel, dim3(grid_for(n_chunks, kBlock)), dim3(kBlock), 0, stream,
+                     (const unsigned short*)in, (unsigned short*)out, n_chunks, C, Cp);
+  return (int)hipGetLastError();
+}

@@ -62,8 +62,10 @@ constexpr int kTileBytes = BM * BK * 2;  // 16 KiB per operand tile
 
 // Convolution geometry (NHWC). x: [N][H][W][CI], dy / y: [N][OH][OW][CO], w: [CO][KH][KW][CI].
 struct ConvGeom {
-  int H, W, OH, OW, S, P, KH, KW, CI, CO;
+  int H, W, OH, OW, S, P, KH, KW, CI, CO;   // S, P: stride and padding along H (and along W unless SW / PW differ)
   int NB;            // images in the batch (row order of the strided data gradient)
+  int SW, PW;        // stride and (left) padding along W; forward and weight gradient only
+  int fold;          // weight gradient: 1 = one launch plane per kernel ROW, its KW taps side by side in N (N = KW * CI)
   float r_ohw, r_ow, r_hw, r_w, r_ci, r_co, r_kw;   // reciprocals for the exact float divmod below
 };
 
@@ -102,6 +104,10 @@ struct GemmArgs {
   const float* bn_scale;
   const float* bn_shift;
   const unsigned char* bn_mask;
+  // up2 (plain products only): row m = (n, a, b) of an [NB][H/2][W/2] grid is stored at pixel (n, 2a, 2b) of an
+  // [NB][H][W] image and zeros at its three neighbours (2a, 2b+1), (2a+1, 2b), (2a+1, 2b+1): the data gradient of a
+  // 1x1 convolution of stride 2 as one GEMM over the pixels that were read. H, W in cv.
+  int up2;
   ConvGeom cv;
 };
 
@@ -179,20 +185,37 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rs, bool ok, 
 // same k-chunk for all 4 chunks of a thread, 32 rows apart).
 // row-contiguous image ([k][row]): row-chunk rc = tid & 15 (rows rc*8..+7), k = (tid >> 4)*4 + i.
 
-template <int T, int GATHER>   // GATHER: 0 plain, 1 conv forward x, 2 conv dgrad dy, 3 conv wgrad x, 4 conv dgrad w
+//
+// ROWS = 128 or 64 rows per tile. A 64-row tile has half the chunks (two per thread); its row-contiguous image keeps
+// the 256-byte k-rows of the 128-row one (only chunks 0..7 are filled), so both read with the same swizzle.
+
+template <int T, int GATHER, int ROWS>   // GATHER: 0 plain, 1 conv forward x, 2 conv dgrad dy, 3 conv wgrad x, 4 conv dgrad w
 struct Stager {
-  u32x4 r[4];
-  int base[4];       // element offset of the row's first tap (GATHER 1, 2; see init)
-  int ca[4], cb[4];  // ih0 / iw0 (GATHER 1) or ih+P / iw+P (GATHER 2)
-  bool rowok[4];
+  static constexpr int NCH = ROWS / 32;    // 16-byte chunks per thread
+  static constexpr int RCB = ROWS == 64 ? 3 : 4;   // T = 1: log2(row chunks per k-row)
+  u32x4 r[NCH];
+  int base[NCH];       // element offset of the row's first tap (GATHER 1, 2; see init)
+  int ca[NCH], cb[NCH];  // ih0 / iw0 (GATHER 1) or ih+P / iw+P (GATHER 2)
+  bool rowok[NCH];
   int tkh, tkw;      // filter tap of this launch plane (GATHER 3)
+  int coff;          // GATHER 3: element offset of this thread's 8 columns inside the source pixel
 
   __device__ __forceinline__ void init(const GemmArgs& g, int rows, int row0, int tap) {
-    if (GATHER == 3) divmod(tap, g.cv.KW, g.cv.r_kw, tkh, tkw);
+    if (GATHER == 3) {
+      const int col = row0 + ((threadIdx.x & ((1 << RCB) - 1)) << 3);
+      if (g.cv.fold) {                       // plane = kernel row; column = (kw, ci)
+        int q, rr;
+        divmod(col < rows ? col : 0, g.cv.CI, g.cv.r_ci, q, rr);
+        tkh = tap; tkw = q; coff = rr;
+      } else {
+        divmod(tap, g.cv.KW, g.cv.r_kw, tkh, tkw);
+        coff = col;
+      }
+    }
     if (T == 0 && (GATHER == 1 || GATHER == 2)) {
       const ConvGeom& c = g.cv;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NCH; ++i) {
         const int row = row0 + ((threadIdx.x + kThreads * i) >> 3);
         rowok[i] = row < rows;
         const int m = rowok[i] ? row : 0;
@@ -200,7 +223,7 @@ struct Stager {
         if (GATHER == 1) {                  // m = (n, oh, ow)
           divmod(m, c.OH * c.OW, c.r_ohw, n, rem);
           divmod(rem, c.OW, c.r_ow, a, b);
-          ca[i] = a * c.S - c.P; cb[i] = b * c.S - c.P;
+          ca[i] = a * c.S - c.P; cb[i] = b * c.SW - c.PW;
           base[i] = ((n * c.H + ca[i]) * c.W + cb[i]) * c.CI;    // element offset of tap (0, 0); may be negative
         } else {                            // m = input pixel, see dgrad_pixel()
           dgrad_pixel(c, m, n, a, b);
@@ -224,7 +247,7 @@ struct Stager {
       const bool kok = k < kend;
       if (GATHER == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NCH; ++i) {
           const int row = row0 + ((threadIdx.x + kThreads * i) >> 3);
           r[i] = buf_load16(rs, row < rows && kok, (unsigned)row * uld + (unsigned)k);
         }
@@ -234,7 +257,7 @@ struct Stager {
         divmod(t, c.KW, c.r_kw, kh, kw);
         const int tapo = (kh * c.W + kw) * c.CI + ci;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NCH; ++i) {
           const int ih = ca[i] + kh, iw = cb[i] + kw;
           const bool ok = rowok[i] && kok && (unsigned)ih < (unsigned)c.H && (unsigned)iw < (unsigned)c.W;
           r[i] = buf_load16(rs, ok, (unsigned)(base[i] + tapo));
@@ -246,14 +269,14 @@ struct Stager {
         if (c.S == 1) {
           const int tapo = co - (kh * c.OW + kw) * c.CO;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < NCH; ++i) {
             const int th = ca[i] - kh, tw = cb[i] - kw;
             const bool ok = rowok[i] && kok && (unsigned)th < (unsigned)c.OH && (unsigned)tw < (unsigned)c.OW;
             r[i] = buf_load16(rs, ok, (unsigned)(base[i] + tapo));
           }
         } else {                                 // S == 2
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < NCH; ++i) {
             const int th = ca[i] - kh, tw = cb[i] - kw;
             const int oh = th >> 1, ow = tw >> 1;
             const bool ok = rowok[i] && kok && th >= 0 && tw >= 0 && !((th | tw) & 1) && oh < c.OH && ow < c.OW;
@@ -262,11 +285,11 @@ struct Stager {
         }
       }
     } else {
-      const int rc = threadIdx.x & 15, kg = threadIdx.x >> 4;
+      const int rc = threadIdx.x & ((1 << RCB) - 1), kg = threadIdx.x >> RCB;
       const int row = row0 + (rc << 3);
       const bool rok = row < rows;
-      const int kf = k0 + kg * 4;           // this thread's first k of the tile; k = kf + i
-      // one divmod per tile; the following three k are reached by increment-with-carry
+      const int kf = k0 + kg * NCH;         // this thread's first k of the tile; k = kf + i
+      // one divmod per tile; the following k are reached by increment-with-carry
       int t = 0, co = 0, n = 0, oh = 0, ow = 0;
       if (GATHER == 4) divmod(kf < kend ? kf : 0, c.CO, c.r_co, t, co);
       if (GATHER == 3) {
@@ -275,7 +298,7 @@ struct Stager {
         divmod(rem, c.OW, c.r_ow, oh, ow);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NCH; ++i) {
         const int k = kf + i;
         const bool ok = rok && k < kend;
         if (GATHER == 0) {
@@ -283,9 +306,9 @@ struct Stager {
         } else if (GATHER == 4) {           // weights for dgrad: k = (tap, co) -> w[co][tap][ci = row]
           r[i] = buf_load16(rs, ok, (unsigned)co * uld + (unsigned)(t * c.CI + row));
         } else {                            // GATHER 3: k = output pixel, tap fixed: x[(n, oh*S+kh-P, ow*S+kw-P)][row]
-          const int ih = oh * c.S + tkh - c.P, iw = ow * c.S + tkw - c.P;
+          const int ih = oh * c.S + tkh - c.P, iw = ow * c.SW + tkw - c.PW;
           r[i] = buf_load16(rs, ok && (unsigned)ih < (unsigned)c.H && (unsigned)iw < (unsigned)c.W,
-                            (unsigned)(((n * c.H + ih) * c.W + iw) * c.CI + row));
+                            (unsigned)(((n * c.H + ih) * c.W + iw) * c.CI + coff));
         }
         if (GATHER == 4) { if (++co == c.CO) { co = 0; ++t; } }
         if (GATHER == 3) { if (++ow == c.OW) { ow = 0; if (++oh == c.OH) { oh = 0; ++n; } } }
@@ -296,15 +319,15 @@ struct Stager {
   __device__ __forceinline__ void store(char* lds) const {
     if (T == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NCH; ++i) {
         const int id = threadIdx.x + kThreads * i;
         *reinterpret_cast<u32x4*>(lds + swz_off(id >> 3, id & 7)) = r[i];
       }
     } else {
-      const int rc = threadIdx.x & 15, kg = threadIdx.x >> 4;
+      const int rc = threadIdx.x & ((1 << RCB) - 1), kg = threadIdx.x >> RCB;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = kg * 4 + i;
+      for (int i = 0; i < NCH; ++i) {
+        const int k = kg * NCH + i;
         *reinterpret_cast<u32x4*>(lds + k * 256 + ((rc ^ swz_t(k)) << 4)) = r[i];
       }
     }
@@ -334,14 +357,22 @@ __device__ __forceinline__ bf16x8_t load_frag(const char* lds, int row0, int ks,
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <int A_T, int B_T, int CONV, int STAGES>
-__global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 tiles: A0 B0 A1 B1 (64 KiB)
+// V selects the output tile: 0 = 128 x 128 (waves 2 x 2, 64 x 64 each), 1 = 128 x 64 (waves 4 x 1, 32 x 64 each) for
+// products at most 64 columns wide (the 64-channel layers of a ResNet, a convolution stem): half the accumulators,
+// half the B tile, four resident blocks per CU instead of three.
+template <int A_T, int B_T, int CONV, int STAGES, int V>
+__global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES x (A tile, B tile)
+  constexpr int BN_ = V ? 64 : 128;          // tile columns
+  constexpr int WTM = V ? 32 : 64;           // rows of a wave's sub-tile
+  constexpr int MI = WTM / 16;               // MFMA tiles per wave along m
+  constexpr int kBTile = (B_T == 1 ? 128 : BN_) * BK * 2;   // bytes of the B image (see Stager)
+  constexpr int kStage = kTileBytes + kBTile;
 
   // ---- block -> tile map: XCD-aware, bijective for any grid size --------------------
   // CONV 3 (weight gradient): the filter taps of one (tile, split) are neighbouring blocks of one XCD,
   // so the dy tile they all read and the overlapping x pixels are served by that XCD's L2.
-  const int ntaps = CONV == 3 ? g.cv.KH * g.cv.KW : 1;
+  const int ntaps = CONV == 3 ? (g.cv.fold ? g.cv.KH : g.cv.KH * g.cv.KW) : 1;
   const int nwg = g.tiles_m * g.tiles_n * ntaps;
   const int orig = blockIdx.x;
   const int xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
@@ -354,7 +385,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   // is reached by 0..4 of the filter taps), while an XCD owns a contiguous range of tiles. Deal the
   // row tiles of the four classes out round-robin so that every XCD gets the same mix.
   if (CONV == 2 && g.cv.S == 2 && (g.tiles_m & 3) == 0) tm = (tm & 3) * (g.tiles_m >> 2) + (tm >> 2);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * BN_;
   const int split = blockIdx.y;
   const int plane = CONV == 3 ? tap : (int)blockIdx.z;
   const int planes = CONV == 3 ? ntaps : (int)gridDim.z;
@@ -367,19 +398,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   const int nt = (kend - kbeg + BK - 1) / BK;
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = V ? wid : wid >> 1, wn = V ? 0 : wid & 1;
   const int fr = lane & 15, fq = lane >> 4;
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   constexpr int GA = CONV == 1 ? 1 : CONV == 2 ? 2 : 0;
   constexpr int GB = CONV == 2 ? 4 : CONV == 3 ? 3 : 0;
-  Stager<A_T, GA> sa;
-  Stager<B_T, GB> sb;
+  Stager<A_T, GA, BM> sa;
+  Stager<B_T, GB, BN_> sb;
   sa.init(g, g.M, m0, tap);
   sb.init(g, g.N, n0, tap);
 
@@ -410,13 +441,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     const char* lb = la + kTileBytes;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t a[4], b[4];
+      bf16x8_t a[MI], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = load_frag<A_T>(la, wm * 64 + i * 16, ks, lane);
+      for (int i = 0; i < MI; ++i) a[i] = load_frag<A_T>(la, wm * WTM + i * 16, ks, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[j] = load_frag<B_T>(lb, wn * 64 + j * 16, ks, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           // swapped operands: result register r of lane l is C[m = i*16 + (l&15)][n = j*16 + (l>>4)*4 + r]
@@ -443,9 +474,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
         sa.load(g, Ap, g.lda, g.M, m0, k0, kend, tap);
         sb.load(g, Bp, g.ldb, g.N, n0, k0, kend, tap);
       }
-      compute(smem + cur * 2 * kTileBytes);
+      compute(smem + cur * kStage);
       if (more) {
-        char* na = smem + (cur ^ 1) * 2 * kTileBytes;
+        char* na = smem + (cur ^ 1) * kStage;
         sa.store(na);
         sb.store(na + kTileBytes);
       }
@@ -478,12 +509,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   }
 
   // ---- epilogue ---------------------------------------------------------------------
-  const int wm0 = m0 + wm * 64, wn0 = n0 + wn * 64;
+  const int wm0 = m0 + wm * WTM, wn0 = n0 + wn * 64;
   if (g.splits > 1) {
     // fp32 partial slab [split][batch][M][N]; 16 bytes per lane, 4 consecutive n
     float* W = reinterpret_cast<float*>(g.C) + ((long long)split * planes + plane) * g.M * g.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int m = wm0 + i * 16 + fr;
       if (m >= g.M) continue;
 #pragma unroll
@@ -510,7 +541,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv[r];
@@ -522,7 +553,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   if (g.drop_thresh) {
     const unsigned long long off = *g.drop_off;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const long long m = wm0 + i * 16 + fr;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -538,7 +569,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   if (g.out_fp32) {
     float* C = reinterpret_cast<float*>(g.C) + c_off;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int m = wm0 + i * 16 + fr;
       if (m >= g.M) continue;
 #pragma unroll
@@ -550,11 +581,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     return;
   }
 
-  // bf16 output: each wave stages its 64x64 tile in its own 8 KiB of LDS ([row][64 n], 128-byte
+  // bf16 output: each wave stages its WTM x 64 tile in its own LDS ([row][64 n], 128-byte
   // rows, same XOR swizzle), then writes whole 128-byte row segments.
-  char* stage = smem + wid * (64 * 128);
+  char* stage = smem + wid * (WTM * 128);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const int row = i * 16 + fr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -605,8 +636,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
   };
   const bool bn_grad_stats = g.col_stats && g.stats_mode == 1;
   if (bn_grad_stats) fetch_bn(0);
+  constexpr int kPasses = WTM / 8;           // 64 lanes x 16 bytes = 8 rows of the sub-tile per pass
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
+  for (int p = 0; p < kPasses; ++p) {
     const int id = lane + 64 * p;
     const int row = id >> 3, chunk = id & 7;
     const int m = wm0 + row, n = wn0 + chunk * 8;
@@ -625,6 +657,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
         int pn, ph, pw;
         dgrad_pixel(g.cv, m, pn, ph, pw);
         mr = ((long long)pn * g.cv.H + ph) * g.cv.W + pw;
+      } else if (CONV == 0 && g.up2) {
+        int pn, rem, a, b;
+        divmod(m, (g.cv.H >> 1) * (g.cv.W >> 1), 4.f * g.cv.r_hw, pn, rem);
+        divmod(rem, g.cv.W >> 1, 2.f * g.cv.r_w, a, b);
+        mr = ((long long)pn * g.cv.H + 2 * a) * g.cv.W + 2 * b;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(C + (mr + 1) * g.ldc + n) = z;
+        *reinterpret_cast<u32x4*>(C + (mr + g.cv.W) * g.ldc + n) = z;
+        *reinterpret_cast<u32x4*>(C + (mr + g.cv.W + 1) * g.ldc + n) = z;
       }
       if (Cin) {
         // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
@@ -664,7 +705,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
         }
       }
     }
-    if (p == 3 && bn_grad_stats) fetch_bn(4);
+    if (p == 3 && kPasses > 4 && bn_grad_stats) fetch_bn(4);
   }
   if (g.col_stats) {
     // combine the 8 lanes that hold the same chunk (lane ^ 8, 16, 32): fixed order, no atomics
@@ -675,7 +716,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs g) {
     }
     const int n = wn0 + lane * 8;
     if (lane < 8 && n < g.N) {
-      float* dst = g.col_stats + ((long long)((m0 / BM) * 2 + wm) * 2) * g.N + n;
+      float* dst = g.col_stats + ((long long)((m0 / BM) * (BM / WTM) + wm) * 2) * g.N + n;
       *reinterpret_cast<f32x4*>(dst) = f32x4{cs0[0], cs0[1], cs0[2], cs0[3]};
       *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs0[4], cs0[5], cs0[6], cs0[7]};
       *reinterpret_cast<f32x4*>(dst + g.N) = f32x4{cs1[0], cs1[1], cs1[2], cs1[3]};
@@ -764,6 +805,11 @@ struct GemmExtra {
   const void* bn_shift;
   const void* bn_mask;
   const void* cin_mask;              // optional ReLU mask bits applied to Cin before it is added
+  int SW, PW;                        // stride / left padding along W when they differ from S / P (0, 0 = same; forward
+  int use_sw;                        //   and weight gradient only); use_sw = 1 makes them count
+  int fold;                          // weight gradient: planes are kernel rows, N = KW * CI (see ConvGeom)
+  int tile;                          // 0 = 128 x 128 output tile, 1 = 128 x 64
+  int up2;                           // plain NN product stored at every other pixel of an [NB][H][W] image (see GemmArgs)
 };
 
 // Sums fp32 split-K slabs [splits][M][N] into C (bias, activation, conversion); shared with gemm256.hip.
@@ -795,10 +841,15 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0; g.drop_off = nullptr;
   g.col_stats = nullptr; g.stats_mode = 0; g.bn_relu = 0;
   g.bn_x = nullptr; g.bn_mean = g.bn_scale = g.bn_shift = nullptr; g.bn_mask = nullptr;
+  g.up2 = 0;
+  const int variant = ex && ex->tile == 1 ? 1 : 0;
+  const int bn_cols = variant ? 64 : BN;
+  g.tiles_n = (N + bn_cols - 1) / bn_cols;
   int batch = 1, conv = 0;
   g.nb2 = 1; g.sA1 = g.sA2 = g.sB1 = g.sB2 = g.sC1 = g.sC2 = 0;
   ConvGeom& c = g.cv;
   c.H = c.W = c.OH = c.OW = c.S = c.KH = c.KW = c.CI = c.CO = c.NB = 1; c.P = 0;
+  c.SW = 1; c.PW = 0; c.fold = 0;
   if (ex) {
     const int nb1 = ex->nb1 > 0 ? ex->nb1 : 1;
     g.nb2 = ex->nb2 > 0 ? ex->nb2 : 1;
@@ -816,7 +867,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
     }
     if (ex->col_stats) {
       // whole-output statistics: one plane, plain row order, bf16 output written by this kernel's own epilogue
-      if (out_fp32 || batch > 1 || ex->conv == 3 || (ex->conv == 2 && ex->S != 1) || N % 8) return -10;
+      if (out_fp32 || batch > 1 || ex->conv == 3 || (ex->conv == 2 && ex->S != 1) || N % 8 || ex->up2) return -10;
       g.col_stats = (float*)ex->col_stats;
       splits = 1;
       if (ex->stats_mode == 1) {
@@ -830,10 +881,23 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
       }
     }
     conv = ex->conv;
+    if (ex->up2) {
+      // rows are the pixels a stride-2 1x1 convolution read: bf16 output written by this kernel's own epilogue
+      if (conv || layout != 1 || out_fp32 || batch > 1 || ex->col_stats || ex->Cin || ((ex->H | ex->W) & 1) ||
+          (long long)M >= (1 << 24) || (long long)M * 4 != (long long)ex->NB * ex->H * ex->W)
+        return -12;
+      g.up2 = 1; c.H = ex->H; c.W = ex->W; c.NB = ex->NB;
+      splits = 1;
+    }
     if (conv) {
       c.H = ex->H; c.W = ex->W; c.OH = ex->OH; c.OW = ex->OW; c.S = ex->S; c.P = ex->P; c.KH = ex->KH; c.KW = ex->KW;
       c.CI = ex->CI; c.CO = ex->CO; c.NB = ex->NB > 0 ? ex->NB : 1;
+      c.SW = ex->use_sw ? ex->SW : c.S; c.PW = ex->use_sw ? ex->PW : c.P;
+      c.fold = conv == 3 && ex->fold ? 1 : 0;
       if (c.S != 1 && c.S != 2) return -4;
+      if (c.SW != 1 && c.SW != 2) return -4;
+      if (conv == 2 && (c.SW != c.S || c.PW != c.P)) return -4;   // the data gradient keeps square strides
+      if (c.fold && (c.CI % 8 || N != c.KW * c.CI)) return -4;
       if (conv == 2 && c.S == 2 && ((c.H | c.W) & 1)) return -7;   // class-ordered rows need even H, W
       if (conv == 2 && out_fp32) return -6;
       if ((long long)M >= (1 << 24) || (long long)K >= (1 << 24)) return -5;   // float divmod range
@@ -865,11 +929,15 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   // buffer and twice the resident blocks. g_stages overrides (1 or 2) for A/B measurements.
   const int k_tiles = kps / BK;
   const int stages = g_stages == 1 || g_stages == 2 ? g_stages : (k_tiles <= kSingleStageTiles ? 1 : 2);
-  const size_t lds = (stages == 2 ? 4 : 2) * kTileBytes;
+  // LDS per stage: A image + B image (a row-contiguous B keeps 256-byte k-rows in either variant)
+  const size_t b_tile = (layout == 0 && variant ? 64 : 128) * BK * 2;
+  const size_t stage_bytes = kTileBytes + b_tile;
+  const size_t lds = (stages == 2 ? 2 : 1) * stage_bytes;
 #define GEMM_LAUNCH(AT, BT, CV)                                                                              \
   do {                                                                                                       \
-    if (stages == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 2>), grid, dim3(kThreads), lds, stream, g); \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 1>), grid, dim3(kThreads), lds, stream, g);        \
+    if (variant) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 1, 1>), grid, dim3(kThreads), lds, stream, g); \
+    else if (stages == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 2, 0>), grid, dim3(kThreads), lds, stream, g); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 1, 0>), grid, dim3(kThreads), lds, stream, g);     \
   } while (0)
   if (conv == 0) {
     switch (layout) {

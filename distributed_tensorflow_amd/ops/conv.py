@@ -1,26 +1,33 @@
 """2-D convolution front end for channels_last (NHWC) activations.
 
-Routing:
-* bf16 convolutions whose channel counts are multiples of 8 (every ResNet layer but the 3-channel
-  stem) run on the hand-written MFMA kernel (``csrc/kernels/gemm.hip``): forward, data gradient
-  and split-K weight gradient are implicit GEMMs on the NHWC bytes. A 1x1 stride-1 convolution
-  (two thirds of ResNet-50's layers) is literally ``y[N*H*W, Cout] = x[N*H*W, Cin] @ w^T``;
-  larger kernels and strides gather the shifted / strided pixels while the operand is staged.
-* everything else (the stem, fp32, odd channel counts) goes to the vendor convolution library.
+Every bf16 convolution on a GPU runs on the hand-written MFMA kernel (``csrc/kernels/gemm.hip``): forward,
+data gradient and split-K weight gradient are implicit GEMMs on the NHWC bytes.
 
-``set_conv1x1_backend`` / ``set_convkxk_backend`` (``'auto' | 'gemm' | 'library'``, defaults from
-the ``DTF_CONV1X1`` / ``DTF_CONVKXK`` environment variables) switch the routes, e.g. for A/B timing.
-``'auto'`` decides per pass from measurements on MI355X (``tools/bench_conv.py``): the forward
-pass always runs on the own kernel; the data gradient of a strided convolution and the passes
-of 64-channel 3x3 layers, where the vendor library measured faster, go to the library.
+* A 1x1 stride-1 convolution (two thirds of ResNet-50's layers) is literally
+  ``y[N*H*W, Cout] = x[N*H*W, Cin] @ w^T``; larger kernels and strides gather the shifted / strided pixels
+  while the operand is staged. Layers at most 64 channels wide run on the 128 x 64 output tile.
+* The data gradient of a 1x1 stride-2 convolution is one plain product over the pixels the forward pass read,
+  stored at every other pixel with zeros written beside it (``up2`` of the kernel).
+* A first layer (input channels not a multiple of 8: grey-scale or RGB images) is zero-padded on the channel
+  axis by a small kernel so that operand chunks are 16 bytes: to 4 channels for a stride-2 layer on an even
+  width -- two neighbouring pixels then form one 8-"channel" pixel of a half-width image, and a ``KW``-tap row
+  becomes ``ceil((KW + P % 2) / 2)`` taps of stride 1 -- and to 8 channels otherwise.
+
+``set_conv1x1_backend`` / ``set_convkxk_backend`` (``'auto' | 'gemm' | 'library'``, defaults from the
+``DTF_CONV1X1`` / ``DTF_CONVKXK`` environment variables) exist for A/B timing against the vendor convolution
+library (``tools/bench_conv.py``); ``'auto'`` and ``'gemm'`` both mean the framework's own kernel for every pass.
+fp32 and CPU tensors take the torch composition.
 """
 from __future__ import annotations
 
 import os
 
+import ctypes
+
 import torch
 import torch.nn.functional as F
 
+from . import _lib
 from . import gemm as _gemm
 
 _backend = os.environ.get("DTF_CONV1X1", "auto")
@@ -61,7 +68,7 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, padding, auto=False, stats=None, grad_req=None):
         """``grad_req``: the ``ops.norm.GradStatsRequest`` of the batch norm that produced ``x``, if any.
-        ``stats`` (optional, filled in place): fp32 ``[gemm.col_stats_rows(M), 2, K]`` partial batch-norm
+        ``stats`` (optional, filled in place): fp32 ``[gemm.col_stats_rows(M, K), 2, K]`` partial batch-norm
         statistics of the output, accumulated in the GEMM's store phase."""
         N, C, H, W = x.shape
         K, _, KH, KW = w.shape
@@ -101,22 +108,22 @@ class _ConvFn(torch.autograd.Function):
                                    "(ops.conv.set_bn_stats(False) disables the hand-over)")
             if not (g_alias.dtype == x.dtype and g_alias.shape == x.shape
                     and g_alias.is_contiguous(memory_format=torch.channels_last)
-                    and ctx.needs_input_grad[0] and not (ctx.auto and stride != 1)):
+                    and ctx.needs_input_grad[0] and not up2_geom(KH, KW, stride, padding, H, W)):
                 g_alias, alias_mask = _apply_mask_bits(g_alias, alias_mask), None
         plain = KH == 1 and KW == 1 and stride == 1 and padding == 0
+        # 1x1, stride 2: the pixels that were read receive dy @ w, their three neighbours zeros
+        up2 = (KH == 1 and KW == 1 and stride == 2 and padding == 0 and H % 2 == 0 and W % 2 == 0
+               and N * OH * OW < (1 << 24))
         gx = gw = None
-        # per-pass routing of 'auto' (see the module docstring)
-        lib_dgrad = ctx.auto and (stride != 1 or (KH * KW > 1 and K < 128))
-        lib_wgrad = ctx.auto and KH * KW > 1 and C < 128
         want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        if (want_x and lib_dgrad) or (want_w and lib_wgrad):
-            mask = [bool(want_x and lib_dgrad), bool(want_w and lib_wgrad), False]
-            lgx, lgw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [stride, stride], [padding, padding],
-                                                              [1, 1], False, [0, 0], 1, mask)
-            if mask[0]:
-                gx, want_x = lgx, False
-            if mask[1]:
-                gw, want_w = lgw, False
+        if want_x and up2:
+            gx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+            ex = _gemm.GemmExtra()
+            ex.nb1 = ex.nb2 = 1
+            ex.up2, ex.H, ex.W, ex.NB = 1, H, W, N
+            _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * OH * OW, C, K, K, C, C, extra=ex)
+            gx = gx.permute(0, 3, 1, 2)
+            want_x = False
         if want_x:
             gx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
             add = add_mask = None
@@ -127,7 +134,7 @@ class _ConvFn(torch.autograd.Function):
             req, part, bn_grad = ctx.grad_req, None, None
             if (_bn_grad_stats and req is not None and req.x is not None and stride == 1 and req.x.shape == x.shape
                     and req.x.dtype == torch.bfloat16 and req.x.is_contiguous(memory_format=torch.channels_last)):
-                part = torch.empty((_gemm.col_stats_rows(N * H * W), 2, C), dtype=torch.float32, device=x.device)
+                part = torch.empty((_gemm.col_stats_rows(N * H * W, C), 2, C), dtype=torch.float32, device=x.device)
                 bn_grad = (req.x, req.stats, req.mask, req.relu)
             if plain:
                 _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, K, K, C, C, add=add, col_stats=part, bn_grad=bn_grad,
@@ -152,6 +159,10 @@ class _ConvFn(torch.autograd.Function):
         return gx, gw, None, None, None, None, None
 
 
+def up2_geom(KH, KW, stride, padding, H, W) -> bool:
+    return KH == 1 and KW == 1 and stride == 2 and padding == 0 and H % 2 == 0 and W % 2 == 0
+
+
 class _ConvForkFn(_ConvFn):
     """``(conv(x, w), alias of x)``: the block input feeds both the first convolution and the identity
     (or down-sampling) branch. Routing the second use through the alias hands its gradient to this
@@ -172,6 +183,124 @@ class _ConvForkFn(_ConvFn):
                 g_alias, tk.masked_grad = _apply_mask_bits(g_alias, tk.masked_grad[1]), None
             return g_alias, None, None, None, None, None, None, None
         return _ConvFn.backward(ctx, gy, g_alias) + (None,)
+
+
+def pad_channels(x: torch.Tensor, cp: int) -> torch.Tensor:
+    """``[N, H, W, cp]`` copy of a channels_last bf16 ``[N, C, H, W]`` activation with zeros in channels ``C..cp``."""
+    N, C, H, W = x.shape
+    if C == cp:
+        return x.permute(0, 2, 3, 1)
+    out = torch.empty((N, H, W, cp), dtype=x.dtype, device=x.device)
+    rc = _lib.kernels().dtf_pad_channels_bf16(_lib.ptr(x), _lib.ptr(out), ctypes.c_longlong(N * H * W), C, cp,
+                                              _lib.stream_ptr(x.device))
+    _lib.check(rc, "pad_channels_bf16")
+    return out
+
+
+class _FirstConvFn(torch.autograd.Function):
+    """Convolution of an image with few channels (not a multiple of 8), see the module docstring: the input is
+    channel-padded once, the weights are padded (and, in the pixel-pair form, shifted) to match, and forward and
+    weight gradient run on the implicit-GEMM kernel; the batch is cut into chunks that respect the kernel's index
+    ranges (2^24 GEMM rows, 2^31 operand elements)."""
+
+    @staticmethod
+    def _geometry(C, H, W, KH, KW, stride, padding):
+        pair = C <= 4 and stride == 2 and W % 2 == 0
+        if pair:
+            shift = padding & 1
+            return dict(pair=True, cp=4, shift=shift, kwv=(KW + shift + 1) // 2, civ=8, wv=W // 2, swv=1,
+                        pwv=(padding + shift) // 2)
+        cp = -(-C // 8) * 8
+        return dict(pair=False, cp=cp, shift=0, kwv=KW, civ=cp, wv=W, swv=stride, pwv=padding)
+
+    @staticmethod
+    def _pad_weight(w, g):
+        K, C, KH, KW = w.shape
+        taps = 2 * g["kwv"] if g["pair"] else KW
+        wp = torch.zeros((K, KH, taps, g["cp"]), dtype=w.dtype, device=w.device)
+        wp[:, :, g["shift"]:g["shift"] + KW, :C] = w.permute(0, 2, 3, 1)
+        return wp
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, stats=None):
+        N, C, H, W = x.shape
+        K, _, KH, KW = w.shape
+        OH = (H + 2 * padding - KH) // stride + 1
+        OW = (W + 2 * padding - KW) // stride + 1
+        g = _FirstConvFn._geometry(C, H, W, KH, KW, stride, padding)
+        xp = pad_channels(x, g["cp"])
+        wp = _FirstConvFn._pad_weight(w, g)
+        kdim = KH * g["kwv"] * g["civ"]
+        y = torch.empty((N, OH, OW, K), dtype=x.dtype, device=x.device)
+        nb = max(1, min(((1 << 24) - 1) // max(OH * OW, 1), ((1 << 31) - 1) // (H * W * g["cp"]),
+                        ((1 << 31) - 1) // (OH * OW * K)))
+        rows = 0
+        for b0 in range(0, N, nb):
+            b1 = min(N, b0 + nb)
+            M = (b1 - b0) * OH * OW
+            ex = _gemm.conv_geom(_gemm.CONV_FWD, H, g["wv"], OH, OW, stride, padding, KH, g["kwv"], g["civ"], K,
+                                 b1 - b0, stride_w=g["swv"], pad_w=g["pwv"])
+            st = None
+            if stats is not None:
+                r = _gemm.col_stats_rows(M, K)
+                st = stats[rows:rows + r]
+                rows += r
+            _gemm.gemm_raw(_gemm.NT, xp[b0:b1], wp, y[b0:b1], M, K, kdim, g["civ"], kdim, K, extra=ex, col_stats=st)
+        ctx.save_for_backward(xp, w)
+        ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, stride, padding, nb)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def stats_rows(x, w, stride, padding) -> int:
+        """Rows of the statistics buffer ``forward`` fills (the batch chunks' partial rows, one after the other)."""
+        N, C, H, W = x.shape
+        K, _, KH, KW = w.shape
+        OH = (H + 2 * padding - KH) // stride + 1
+        OW = (W + 2 * padding - KW) // stride + 1
+        cp = 4 if (C <= 4 and stride == 2 and W % 2 == 0) else -(-C // 8) * 8
+        nb = max(1, min(((1 << 24) - 1) // max(OH * OW, 1), ((1 << 31) - 1) // (H * W * cp),
+                        ((1 << 31) - 1) // (OH * OW * K)))
+        return sum(_gemm.col_stats_rows((min(N, b0 + nb) - b0) * OH * OW, K) for b0 in range(0, N, nb))
+
+    @staticmethod
+    def backward(ctx, gy):
+        xp, w = ctx.saved_tensors
+        N, C, H, W, K, KH, KW, OH, OW, stride, padding, nb = ctx.geom
+        g = _FirstConvFn._geometry(C, H, W, KH, KW, stride, padding)
+        if not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.contiguous(memory_format=torch.channels_last)
+        gyn = gy.permute(0, 2, 3, 1)
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            ncol = g["kwv"] * g["civ"]
+            fold = ncol <= 64
+            chunks = range(0, N, nb)
+            acc = None
+            for b0 in chunks:
+                b1 = min(N, b0 + nb)
+                ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, g["wv"], OH, OW, stride, padding, KH, g["kwv"], g["civ"], K,
+                                     b1 - b0, stride_w=g["swv"], pad_w=g["pwv"], fold=fold)
+                part = torch.empty((K, KH * ncol), dtype=w.dtype if len(chunks) == 1 else torch.float32,
+                                   device=w.device)
+                _gemm.gemm_raw(_gemm.TN, gyn[b0:b1], xp[b0:b1], part, K, ncol if fold else g["civ"],
+                               (b1 - b0) * OH * OW, K, g["civ"], KH * ncol, extra=ex)
+                acc = part if acc is None else acc + part
+            taps = 2 * g["kwv"] if g["pair"] else KW
+            gw = acc.view(K, KH, taps, g["cp"])[:, :, g["shift"]:g["shift"] + KW, :C].permute(0, 3, 1, 2).to(w.dtype)
+        if ctx.needs_input_grad[0]:
+            # gradient of the image itself (rare): data gradient against 8-channel padded weights, then cut
+            cp8 = -(-C // 8) * 8
+            w8 = torch.zeros((K, KH, KW, cp8), dtype=w.dtype, device=w.device)
+            w8[..., :C] = w.permute(0, 2, 3, 1)
+            gx8 = torch.empty((N, H, W, cp8), dtype=gy.dtype, device=gy.device)
+            nbx = max(1, min(((1 << 24) - 1) // (H * W), ((1 << 31) - 1) // (OH * OW * K)))
+            for b0 in range(0, N, nbx):
+                b1 = min(N, b0 + nbx)
+                ex = _gemm.conv_geom(_gemm.CONV_DGRAD, H, W, OH, OW, stride, padding, KH, KW, cp8, K, b1 - b0)
+                _gemm.gemm_raw(_gemm.NN, gyn[b0:b1], w8, gx8[b0:b1], (b1 - b0) * H * W, cp8, KH * KW * K, K,
+                               KH * KW * cp8, cp8, extra=ex)
+            gx = gx8[..., :C].permute(0, 3, 1, 2)
+        return gx, gw, None, None, None
 
 
 def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -218,11 +347,19 @@ def _own_path(x, w, stride, backend) -> bool:
             and (stride == 1 or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)))
 
 
+def _first_layer_path(x, w, stride, backend) -> bool:
+    """Few-channel image input (see :class:`_FirstConvFn`)."""
+    return (backend != "library" and stride in (1, 2) and x.is_cuda and x.dtype == torch.bfloat16
+            and w.dtype == torch.bfloat16 and x.shape[1] % 8 != 0 and x.shape[1] <= 64 and w.shape[0] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and (stride == 1 or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)))
+
+
 def _stats_buffer(x, w, stride, padding):
     N, _, H, W = x.shape
     K, _, KH, KW = w.shape
     M = N * ((H + 2 * padding - KH) // stride + 1) * ((W + 2 * padding - KW) // stride + 1)
-    return torch.empty((_gemm.col_stats_rows(M), 2, K), dtype=torch.float32, device=x.device)
+    return torch.empty((_gemm.col_stats_rows(M, K), 2, K), dtype=torch.float32, device=x.device)
 
 
 def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0, bn_stats: bool = False):
@@ -236,6 +373,13 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0, 
     if _own_path(x, w, stride, backend):
         st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
         y = _ConvFn.apply(x, w, stride, padding, backend == "auto", st, _norm_request(x))
+        return (y, st) if bn_stats else y
+    if _first_layer_path(x, w, stride, backend):
+        st = None
+        if bn_stats and _bn_stats:
+            st = torch.empty((_FirstConvFn.stats_rows(x, w, stride, padding), 2, w.shape[0]), dtype=torch.float32,
+                             device=x.device)
+        y = _FirstConvFn.apply(x, w, stride, padding, st)
         return (y, st) if bn_stats else y
     if x.dtype != w.dtype:
         x = x.to(w.dtype)

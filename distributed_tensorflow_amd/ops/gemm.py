@@ -54,23 +54,36 @@ class GemmExtra(ctypes.Structure):
                 ("drop_off", ctypes.c_void_p), ("col_stats", ctypes.c_void_p),
                 ("stats_mode", ctypes.c_int), ("bn_relu", ctypes.c_int), ("bn_x", ctypes.c_void_p),
                 ("bn_mean", ctypes.c_void_p), ("bn_scale", ctypes.c_void_p), ("bn_shift", ctypes.c_void_p),
-                ("bn_mask", ctypes.c_void_p), ("cin_mask", ctypes.c_void_p)]
+                ("bn_mask", ctypes.c_void_p), ("cin_mask", ctypes.c_void_p),
+                ("SW", ctypes.c_int), ("PW", ctypes.c_int), ("use_sw", ctypes.c_int), ("fold", ctypes.c_int),
+                ("tile", ctypes.c_int), ("up2", ctypes.c_int)]
 
 
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 1, 2, 3
 
 
 def conv_geom(mode: int, H: int, W: int, OH: int, OW: int, stride: int, pad: int, KH: int, KW: int, CI: int,
-              CO: int, NB: int = 1) -> GemmExtra:
-    """Geometry of an NHWC convolution for the implicit-GEMM modes of the kernel (``NB`` images)."""
+              CO: int, NB: int = 1, stride_w: int | None = None, pad_w: int | None = None,
+              fold: bool = False) -> GemmExtra:
+    """Geometry of an NHWC convolution for the implicit-GEMM modes of the kernel (``NB`` images).
+    ``stride_w`` / ``pad_w``: stride and left padding along W when they differ from those along H (forward and
+    weight gradient). ``fold`` (weight gradient): one launch plane per kernel row with its ``KW`` taps side by
+    side in the output columns (``N = KW * CI``) instead of one plane per tap -- for narrow ``CI``."""
     ex = GemmExtra()
     ex.nb1 = ex.nb2 = 1
     ex.conv = mode
     ex.NB = NB
     ex.H, ex.W, ex.OH, ex.OW, ex.S, ex.P, ex.KH, ex.KW, ex.CI, ex.CO = H, W, OH, OW, stride, pad, KH, KW, CI, CO
-    if mode == CONV_WGRAD:       # one launch plane per filter tap; tap t writes columns [t*CI, (t+1)*CI) of dW
-        ex.nb2 = KH * KW
-        ex.sC2 = CI
+    if stride_w is not None or pad_w is not None:
+        ex.use_sw = 1
+        ex.SW = stride if stride_w is None else stride_w
+        ex.PW = pad if pad_w is None else pad_w
+    if mode == CONV_WGRAD:
+        if fold:                 # plane kh writes columns [kh*KW*CI, (kh+1)*KW*CI) of dW
+            ex.fold, ex.nb2, ex.sC2 = 1, KH, KW * CI
+        else:                    # one launch plane per filter tap; tap t writes columns [t*CI, (t+1)*CI) of dW
+            ex.nb2 = KH * KW
+            ex.sC2 = CI
     return ex
 
 
@@ -98,9 +111,19 @@ def _workspace(device, numel: int) -> torch.Tensor:
     return ws
 
 
+def tile_variant(N: int) -> int:
+    """Output tile of a product ``N`` columns wide: 1 = 128 x 64 (at most 64 columns: half the accumulators and
+    B tile, four resident blocks per CU), 0 = 128 x 128."""
+    return 1 if (_narrow_tile and N <= 64) else 0
+
+
+_narrow_tile = os.environ.get("DTF_GEMM_TILE64", "1") == "1"
+
+
 def _pick_splits(M: int, N: int, K: int) -> int:
     """Split-K factor: enough blocks for 3-4 per CU, at least 8 k-tiles (512 deep) per split."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    bn = 64 if tile_variant(N) else 128
+    tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
     if tiles >= _N_CU or K <= 1024:
         return 1
     # few output tiles and a very long contraction (convolution weight gradients over a large batch) are pure
@@ -122,9 +145,14 @@ def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, s
     if N % 8 or ldc % 8 or out.data_ptr() % 16:
         raise ValueError("gemm output needs N % 8 == 0 and a 16-byte aligned row-major buffer")
     batch = 1
+    if tile_variant(N):
+        if extra is None:
+            extra = GemmExtra()
+            extra.nb1 = extra.nb2 = 1
+        extra.tile = 1
     if extra is not None:
         batch = max(1, extra.nb1) * max(1, extra.nb2)
-        if extra.Cin or (batch > 1 and extra.conv != CONV_WGRAD) or (extra.conv == CONV_DGRAD and extra.S == 2):
+        if extra.up2 or extra.Cin or (batch > 1 and extra.conv != CONV_WGRAD) or (extra.conv == CONV_DGRAD and extra.S == 2):
             splits = 1
     if splits is None:
         splits = _pick_splits(M * batch if batch > 1 else M, N, K)
@@ -268,9 +296,10 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=N
                    splits, out)
 
 
-def col_stats_rows(M: int) -> int:
-    """Rows of the column-statistics buffer of an ``M``-row product: two 64-row wave tiles per 128-row tile."""
-    return 2 * ((M + 127) // 128)
+def col_stats_rows(M: int, N: int) -> int:
+    """Rows of the column-statistics buffer of an ``M x N`` product: one per wave sub-tile, i.e. two 64-row
+    sub-tiles per 128-row tile, four 32-row ones when the product runs on the 128 x 64 tile."""
+    return (4 if tile_variant(N) else 2) * ((M + 127) // 128)
 
 
 def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int,
@@ -279,13 +308,13 @@ def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M
              add_mask: torch.Tensor | None = None):
     """Unchecked launch on explicit dimensions and leading dimensions (batched attention products,
     implicit-GEMM convolutions). ``add`` is a bf16 tensor laid out like ``out`` that is added to the
-    result in the epilogue. ``col_stats`` (fp32 ``[2 * ceil(M / 128), 2, N]``, see :func:`col_stats_rows`)
+    result in the epilogue. ``col_stats`` (fp32 ``[col_stats_rows(M, N), 2, N]``)
     receives per-wave-row column sums and sums of squares of the bf16 output, the partial statistics of a
     batch norm that follows. The caller guarantees 16-byte alignment of every row it addresses."""
     if col_stats is not None:
         if (col_stats.dtype != torch.float32 or not col_stats.is_contiguous() or out.dtype != torch.bfloat16
-                or tuple(col_stats.shape) != (col_stats_rows(M), 2, N)):
-            raise ValueError("gemm_raw: col_stats must be a contiguous fp32 [col_stats_rows(M), 2, N] tensor")
+                or tuple(col_stats.shape) != (col_stats_rows(M, N), 2, N)):
+            raise ValueError("gemm_raw: col_stats must be a contiguous fp32 [col_stats_rows(M, N), 2, N] tensor")
         if extra is None:
             extra = GemmExtra()
             extra.nb1 = extra.nb2 = 1

@@ -257,32 +257,51 @@ def test_batch_norm_act_matches_torch(N, C, H, W, relu, use_res):
     (4, 64, 14, 14, 256, 1, 1, 0), (4, 64, 14, 14, 256, 1, 2, 0), (3, 64, 15, 13, 64, 3, 1, 1),
     (2, 128, 28, 28, 128, 3, 2, 1), (2, 8, 33, 31, 64, 7, 2, 3), (5, 256, 7, 7, 512, 3, 1, 1),
     (2, 16, 32, 32, 32, 3, 2, 1), (1, 512, 9, 9, 24, 3, 1, 0),
+    # 128 x 64 output tile (at most 64 columns in some pass), odd edges
+    (3, 256, 20, 20, 64, 1, 1, 0), (2, 64, 30, 34, 64, 3, 2, 1), (3, 40, 11, 9, 48, 3, 1, 1), (2, 64, 12, 12, 200, 1, 1, 0),
+    # 1x1 stride 2: data gradient as one product stored at every other pixel
+    (3, 256, 28, 28, 512, 1, 2, 0), (2, 72, 10, 6, 40, 1, 2, 0),
+    # first layers: pixel-pair form (<= 4 channels, stride 2, even width) and 8-channel padding
+    (3, 3, 64, 64, 64, 7, 2, 3), (2, 3, 38, 30, 32, 5, 2, 2), (2, 1, 28, 28, 32, 3, 2, 1), (2, 4, 16, 20, 16, 2, 2, 0),
+    (4, 3, 32, 32, 16, 3, 1, 1), (5, 1, 28, 28, 32, 3, 1, 0), (2, 3, 17, 15, 24, 3, 1, 1), (2, 12, 17, 15, 24, 3, 1, 1),
 ])
-def test_implicit_gemm_conv_matches_library(cfg):
+def test_implicit_gemm_conv_matches_fp32_autograd(cfg):
+    """y, dx and dw of the framework's convolution against fp32 torch autograd on the same bf16-rounded inputs."""
     from distributed_tensorflow_amd.ops import conv
     N, C, H, W, K, k, stride, pad = cfg
     torch.manual_seed(sum(cfg))
     x = torch.randn(N, C, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(K, C, k, k, device=DEV) * (1.0 / math.sqrt(C * k * k))).to(torch.bfloat16)
     w = w.contiguous(memory_format=torch.channels_last)
-    outs = {}
-    for be in ("gemm", "auto", "library"):
+    xr = x.float().requires_grad_(True); wr = w.float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, None, stride, pad)
+    dy = torch.randn(yr.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).to(torch.bfloat16)
+    yr.backward(dy.float())
+    ref = (yr.detach(), xr.grad, wr.grad)
+    for be in ("gemm", "auto"):
         conv.set_conv1x1_backend(be); conv.set_convkxk_backend(be)
         x1 = x.clone().requires_grad_(True); w1 = w.clone().requires_grad_(True)
         y = conv.conv2d(x1, w1, stride, pad)
-        dy = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).to(torch.bfloat16)
+        assert y.shape == yr.shape and y.dtype == torch.bfloat16
         y.backward(dy)
-        outs[be] = (y.float(), x1.grad.float(), w1.grad.float())
+        for a, b, name in zip((y.float(), x1.grad.float(), w1.grad.float()), ref, ("y", "dx", "dw")):
+            scale = max(1.0, float(b.abs().max()))
+            torch.testing.assert_close(a / scale, b / scale, rtol=2e-2, atol=1e-2,
+                                       msg=lambda m: be + " " + name + ": " + m)
     conv.set_conv1x1_backend("auto"); conv.set_convkxk_backend("auto")
-    # fp32 reference for the tolerance scale
-    yr = torch.nn.functional.conv2d(x.float(), w.float(), None, stride, pad)
-    assert outs["gemm"][0].shape == yr.shape
-    torch.testing.assert_close(outs["gemm"][0], yr, rtol=2e-2, atol=3e-2)
-    for own in ("gemm", "auto"):
-        for a, b, name in zip(outs[own], outs["library"], ("y", "dx", "dw")):
-            scale = max(1.0, float(b.detach().abs().max()))
-            torch.testing.assert_close(a / scale, b / scale, rtol=3e-2, atol=2e-2,
-                                       msg=lambda m: own + " " + name + ": " + m)
+
+
+def test_first_layer_conv_hands_over_batch_norm_statistics():
+    """The few-channel first layer fills the partial-statistics rows like any other convolution."""
+    from distributed_tensorflow_amd.ops import conv
+    torch.manual_seed(5)
+    x = torch.randn(6, 3, 32, 32, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, device=DEV) * 0.1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y, st = conv.conv2d(x, w, 2, 3, bn_stats=True)
+    assert st is not None
+    yf = y.float().permute(0, 2, 3, 1).reshape(-1, 64)
+    torch.testing.assert_close(st[:, 0].sum(0), yf.sum(0), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(st[:, 1].sum(0), (yf * yf).sum(0), rtol=1e-3, atol=1e-2)
 
 
 def test_gemm_epilogue_accumulates_onto_existing_tensor():
@@ -788,6 +807,11 @@ def test_norm_backward_sums_from_the_consuming_convolution(block):
     conv.set_conv1x1_backend("gemm")
     conv.set_convkxk_backend("gemm")
     grads = {}
+    with torch.no_grad():
+        n_out = net(x).numel()
+    # positive loss weights: the parameter gradients are sums without wholesale cancellation, so bf16 rounding of
+    # the activations shows up as a relative error of about a percent instead of ten
+    wts = torch.rand(n_out, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) + 0.5
     try:
         for tag, fwd, grad in (("none", False, False), ("fwd", True, False), ("both", True, True)):
             conv.set_bn_stats(fwd, grad)
@@ -795,7 +819,7 @@ def test_norm_backward_sums_from_the_consuming_convolution(block):
                 p.grad = None
             xi = x.clone().requires_grad_(True)
             out = net(xi)
-            (out.float() * torch.linspace(-1, 1, out.numel(), device=DEV).reshape(out.shape)).sum().backward()
+            (out.float() * wts.reshape(out.shape)).sum().backward()
             grads[tag] = {n: p.grad.float().clone() for n, p in net.named_parameters()}
             grads[tag]["input"] = xi.grad.float().clone()
     finally:
@@ -803,14 +827,55 @@ def test_norm_backward_sums_from_the_consuming_convolution(block):
         conv.set_conv1x1_backend(saved[0])
         conv.set_convkxk_backend(saved[1])
 
+    # fp32 reference: the same blocks from torch's fp32 convolution / batch norm on the bf16-rounded weights
+    def bn(m, t, res=None):
+        y = torch.nn.functional.batch_norm(t, None, None, m.weight.float(), m.bias.float(), True, 0.1, m.eps)
+        y = y.to(t.dtype)
+        if res is not None:
+            y = y + res
+        return torch.relu(y) if m.relu else y
+
+    def cv(m, t):
+        return torch.nn.functional.conv2d(t, m.weight.to(t.dtype), None, m.stride, m.padding)
+
+    def ref_forward(t):
+        for blk in net:
+            idt = t if blk.down is None else bn(blk.down_bn, cv(blk.down, t))
+            y = bn(blk.bn1, cv(blk.conv1, t))
+            if block == "bottleneck":
+                y = bn(blk.bn2, cv(blk.conv2, y))
+                t = bn(blk.bn3, cv(blk.conv3, y), idt)
+            else:
+                t = bn(blk.bn2, cv(blk.conv2, y), idt)
+        return t
+
+    def torch_grads(dtype):
+        for p in net.parameters():
+            p.grad = None
+        xr = x.to(dtype).requires_grad_(True)
+        outr = ref_forward(xr)
+        (outr.float() * wts.reshape(outr.shape)).sum().backward()
+        g = {n: p.grad.float().clone() for n, p in net.named_parameters()}
+        g["input"] = xr.grad.float().clone()
+        return g
+
+    ref = torch_grads(torch.float32)
+    stock = torch_grads(torch.bfloat16)      # torch's own bf16 evaluation: the yardstick for bf16 rounding
+
     def rel(a, r):
         return float((a - r).norm() / (r.norm() + 1e-12))
-    for n in grads["none"]:
+    print("worst relative L2 error against fp32:",
+          {tag: max(rel(g[n], ref[n]) for n in ref) for tag, g in list(grads.items()) + [("torch-bf16", stock)]})
+    for n in ref:
         # same forward, the norm's backward sums taken in the GEMM or by the norm: only the summation order differs
         assert rel(grads["both"][n], grads["fwd"][n]) < 5e-3, (n, rel(grads["both"][n], grads["fwd"][n]))
-        # against the fully unfused path the forward statistics differ in the last bits, which this deliberately
-        # ill-conditioned loss amplifies (both are ~10 % from an fp32 run); a wrong sum would be far outside
-        assert rel(grads["both"][n], grads["none"][n]) < 8e-2, (n, rel(grads["both"][n], grads["none"][n]))
+        # every path is a bf16 evaluation of the same function (gradients through batch norms cancel heavily, so
+        # bf16 activations cost 10-20 % on the early layers, for torch's bf16 kernels as for these): no further from
+        # the fp32 gradients than 1.6 x torch's bf16 evaluation of the same blocks plus two percent -- the two are
+        # independent roundings, so their ratio scatters; a wrong partial sum is off by the size of the gradient
+        for tag in grads:
+            assert rel(grads[tag][n], ref[n]) < 1.6 * rel(stock[n], ref[n]) + 2e-2, \
+                (tag, n, rel(grads[tag][n], ref[n]), rel(stock[n], ref[n]))
 
 
 @pytest.mark.gpu

@@ -1,6 +1,6 @@
 """Times forward / data-gradient / weight-gradient of single convolutions, own kernel vs vendor library.
 
-usage: python tools/bench_conv.py            (ResNet-50 batch-256 strided and 3x3 shapes)
+usage: python tools/bench_conv.py [batch]    (ResNet-50 strided and 3x3 shapes, batch 256 by default)
 """
 import os
 import sys
@@ -27,12 +27,14 @@ def timeit(fn, iters=10, warmup=3):
 
 
 def main():
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     shapes = [  # N, CI, H, W, CO, k, stride, pad
         (256, 256, 56, 56, 512, 1, 2, 0), (256, 512, 28, 28, 1024, 1, 2, 0), (256, 1024, 14, 14, 2048, 1, 2, 0),
         (256, 128, 56, 56, 128, 3, 2, 1), (256, 256, 28, 28, 256, 3, 2, 1), (256, 512, 14, 14, 512, 3, 2, 1),
         (256, 64, 56, 56, 64, 3, 1, 1), (256, 128, 28, 28, 128, 3, 1, 1), (256, 256, 14, 14, 256, 3, 1, 1),
         (256, 512, 7, 7, 512, 3, 1, 1),
     ]
+    shapes = [(nb,) + t[1:] for t in shapes]
     print(f"{'shape':44s} {'backend':8s} {'fwd_us':>8s} {'dgrad_us':>9s} {'wgrad_us':>9s}")
     for (N, CI, H, W, CO, k, s, p) in shapes:
         x = torch.randn(N, CI, H, W, device=DEV).bfloat16().to(memory_format=torch.channels_last).requires_grad_(True)
