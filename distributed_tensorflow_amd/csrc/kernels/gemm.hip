@@ -22,6 +22,10 @@
 //   CONV=2 dgrad   : M = input pixels,  K = (kh, kw, co), A = dy gathered, B = w per tap    (NN)
 //   CONV=3 wgrad   : per tap (blockIdx.z): M = co, N = ci, K = output pixels,
 //                    A = dy, B = x gathered                                                  (TN)
+//   CONV=4 wgrad^T : one plane: M = (kh, kw, ci), N = co, K = output pixels,
+//                    A = x gathered, B = dy; the result is dW transposed, [KH*KW*CI][CO]      (TN)
+//                    -- for narrow layers (CO <= 64): dy is re-read once per 128 taps x channels
+//                    instead of once per tap
 // so 1x1, 3x3, 7x7, stride 1 or 2 all run on the MFMA main loop below.
 //
 // Structure (tiled for 64-lane wavefronts, not a warp-shaped port):
@@ -65,7 +69,8 @@ struct ConvGeom {
   int H, W, OH, OW, S, P, KH, KW, CI, CO;   // S, P: stride and padding along H (and along W unless SW / PW differ)
   int NB;            // images in the batch (row order of the strided data gradient)
   int SW, PW;        // stride and (left) padding along W; forward and weight gradient only
-  int fold;          // weight gradient: 1 = one launch plane per kernel ROW, its KW taps side by side in N (N = KW * CI)
+  int fold;          // weight gradient: 1 = one launch plane per kernel ROW, its KW taps side by side in N (N = KW * CI);
+                     // 2 = every tap side by side (CONV 4: the gathered operand's columns are (kh, kw, ci))
   float r_ohw, r_ow, r_hw, r_w, r_ci, r_co, r_kw;   // reciprocals for the exact float divmod below
 };
 
@@ -203,10 +208,11 @@ struct Stager {
   __device__ __forceinline__ void init(const GemmArgs& g, int rows, int row0, int tap) {
     if (GATHER == 3) {
       const int col = row0 + ((threadIdx.x & ((1 << RCB) - 1)) << 3);
-      if (g.cv.fold) {                       // plane = kernel row; column = (kw, ci)
+      if (g.cv.fold) {                       // plane = kernel row; column = (kw, ci), or (kh, kw, ci) when fold = 2
         int q, rr;
         divmod(col < rows ? col : 0, g.cv.CI, g.cv.r_ci, q, rr);
         tkh = tap; tkw = q; coff = rr;
+        if (g.cv.fold == 2) divmod(q, g.cv.KW, g.cv.r_kw, tkh, tkw);
       } else {
         divmod(tap, g.cv.KW, g.cv.r_kw, tkh, tkw);
         coff = col;
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int GA = CONV == 1 ? 1 : CONV == 2 ? 2 : 0;
+  constexpr int GA = CONV == 1 ? 1 : CONV == 2 ? 2 : CONV == 4 ? 3 : 0;
   constexpr int GB = CONV == 2 ? 4 : CONV == 3 ? 3 : 0;
   Stager<A_T, GA, BM> sa;
   Stager<B_T, GB, BN_> sb;
@@ -867,7 +873,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
     }
     if (ex->col_stats) {
       // whole-output statistics: one plane, plain row order, bf16 output written by this kernel's own epilogue
-      if (out_fp32 || batch > 1 || ex->conv == 3 || (ex->conv == 2 && ex->S != 1) || N % 8 || ex->up2) return -10;
+      if (out_fp32 || batch > 1 || ex->conv >= 3 || (ex->conv == 2 && ex->S != 1) || N % 8 || ex->up2) return -10;
       g.col_stats = (float*)ex->col_stats;
       splits = 1;
       if (ex->stats_mode == 1) {
@@ -893,11 +899,12 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
       c.H = ex->H; c.W = ex->W; c.OH = ex->OH; c.OW = ex->OW; c.S = ex->S; c.P = ex->P; c.KH = ex->KH; c.KW = ex->KW;
       c.CI = ex->CI; c.CO = ex->CO; c.NB = ex->NB > 0 ? ex->NB : 1;
       c.SW = ex->use_sw ? ex->SW : c.S; c.PW = ex->use_sw ? ex->PW : c.P;
-      c.fold = conv == 3 && ex->fold ? 1 : 0;
+      c.fold = conv == 3 && ex->fold ? 1 : conv == 4 ? 2 : 0;
+      if (conv == 4 && (c.CI % 8 || M != c.KH * c.KW * c.CI || batch > 1)) return -4;
       if (c.S != 1 && c.S != 2) return -4;
       if (c.SW != 1 && c.SW != 2) return -4;
       if (conv == 2 && (c.SW != c.S || c.PW != c.P)) return -4;   // the data gradient keeps square strides
-      if (c.fold && (c.CI % 8 || N != c.KW * c.CI)) return -4;
+      if (c.fold == 1 && (c.CI % 8 || N != c.KW * c.CI)) return -4;
       if (conv == 2 && c.S == 2 && ((c.H | c.W) & 1)) return -7;   // class-ordered rows need even H, W
       if (conv == 2 && out_fp32) return -6;
       if ((long long)M >= (1 << 24) || (long long)K >= (1 << 24)) return -5;   // float divmod range
@@ -909,7 +916,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   {
     // operands are addressed with 32-bit byte offsets: each must span less than 4 GiB
     const long long lim = 1ll << 31;   // elements
-    const long long a_el = conv == 1 ? (long long)c.NB * c.H * c.W * c.CI
+    const long long a_el = conv == 1 || conv == 4 ? (long long)c.NB * c.H * c.W * c.CI
                          : conv == 2 ? (long long)c.NB * c.OH * c.OW * c.CO
                                      : (long long)(layout == 2 ? K : M) * lda;
     const long long b_el = conv == 3 ? (long long)c.NB * c.H * c.W * c.CI : (long long)(layout == 0 ? N : K) * ldb;
@@ -949,6 +956,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   } else if (conv == 1 && layout == 0) GEMM_LAUNCH(0, 0, 1);
   else if (conv == 2 && layout == 1) GEMM_LAUNCH(0, 1, 2);
   else if (conv == 3 && layout == 2) GEMM_LAUNCH(1, 1, 3);
+  else if (conv == 4 && layout == 2) GEMM_LAUNCH(1, 1, 4);
   else return -1;
 #undef GEMM_LAUNCH
   if (splits > 1) {

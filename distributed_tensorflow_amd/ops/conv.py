@@ -152,6 +152,13 @@ class _ConvFn(torch.autograd.Function):
             gw = torch.empty((K, KH, KW, C), dtype=w.dtype, device=x.device)
             if plain:
                 _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, C)
+            elif K <= 64 and _wgrad_t:
+                # narrow layer: the transposed product, every tap side by side in the rows (dy is re-read once per
+                # 128 of them instead of once per tap)
+                ex = _gemm.conv_geom(_gemm.CONV_WGRAD_T, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
+                gwt = torch.empty((KH * KW * C, K), dtype=w.dtype, device=x.device)
+                _gemm.gemm_raw(_gemm.TN, x, gy, gwt, KH * KW * C, K, N * OH * OW, C, K, K, extra=ex)
+                gw = gwt.t().contiguous().view(K, KH, KW, C)
             else:
                 ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex)
@@ -278,13 +285,22 @@ class _FirstConvFn(torch.autograd.Function):
             acc = None
             for b0 in chunks:
                 b1 = min(N, b0 + nb)
-                ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, g["wv"], OH, OW, stride, padding, KH, g["kwv"], g["civ"], K,
-                                     b1 - b0, stride_w=g["swv"], pad_w=g["pwv"], fold=fold)
-                part = torch.empty((K, KH * ncol), dtype=w.dtype if len(chunks) == 1 else torch.float32,
-                                   device=w.device)
-                _gemm.gemm_raw(_gemm.TN, gyn[b0:b1], xp[b0:b1], part, K, ncol if fold else g["civ"],
-                               (b1 - b0) * OH * OW, K, g["civ"], KH * ncol, extra=ex)
+                pdt = w.dtype if len(chunks) == 1 else torch.float32
+                if K <= 64 and _wgrad_t:      # transposed product, every tap side by side in the rows
+                    ex = _gemm.conv_geom(_gemm.CONV_WGRAD_T, H, g["wv"], OH, OW, stride, padding, KH, g["kwv"],
+                                         g["civ"], K, b1 - b0, stride_w=g["swv"], pad_w=g["pwv"])
+                    part = torch.empty((KH * ncol, K), dtype=pdt, device=w.device)
+                    _gemm.gemm_raw(_gemm.TN, xp[b0:b1], gyn[b0:b1], part, KH * ncol, K, (b1 - b0) * OH * OW, g["civ"],
+                                   K, K, extra=ex)
+                    part = part.t()
+                else:
+                    ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, g["wv"], OH, OW, stride, padding, KH, g["kwv"], g["civ"],
+                                         K, b1 - b0, stride_w=g["swv"], pad_w=g["pwv"], fold=fold)
+                    part = torch.empty((K, KH * ncol), dtype=pdt, device=w.device)
+                    _gemm.gemm_raw(_gemm.TN, gyn[b0:b1], xp[b0:b1], part, K, ncol if fold else g["civ"],
+                                   (b1 - b0) * OH * OW, K, g["civ"], KH * ncol, extra=ex)
                 acc = part if acc is None else acc + part
+            acc = acc.contiguous()
             taps = 2 * g["kwv"] if g["pair"] else KW
             gw = acc.view(K, KH, taps, g["cp"])[:, :, g["shift"]:g["shift"] + KW, :C].permute(0, 3, 1, 2).to(w.dtype)
         if ctx.needs_input_grad[0]:
@@ -313,6 +329,7 @@ def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
 
 
 _bn_stats = os.environ.get("DTF_CONV_BN_STATS", "1") != "0"
+_wgrad_t = os.environ.get("DTF_CONV_WGRAD_T", "1") != "0"     # transposed weight gradient of narrow layers (A/B switch)
 
 
 _bn_grad_stats = os.environ.get("DTF_CONV_BN_GRAD_STATS", "1") != "0"

@@ -59,7 +59,7 @@ class GemmExtra(ctypes.Structure):
                 ("tile", ctypes.c_int), ("up2", ctypes.c_int)]
 
 
-CONV_FWD, CONV_DGRAD, CONV_WGRAD = 1, 2, 3
+CONV_FWD, CONV_DGRAD, CONV_WGRAD, CONV_WGRAD_T = 1, 2, 3, 4
 
 
 def conv_geom(mode: int, H: int, W: int, OH: int, OW: int, stride: int, pad: int, KH: int, KW: int, CI: int,
@@ -68,7 +68,8 @@ def conv_geom(mode: int, H: int, W: int, OH: int, OW: int, stride: int, pad: int
     """Geometry of an NHWC convolution for the implicit-GEMM modes of the kernel (``NB`` images).
     ``stride_w`` / ``pad_w``: stride and left padding along W when they differ from those along H (forward and
     weight gradient). ``fold`` (weight gradient): one launch plane per kernel row with its ``KW`` taps side by
-    side in the output columns (``N = KW * CI``) instead of one plane per tap -- for narrow ``CI``."""
+    side in the output columns (``N = KW * CI``) instead of one plane per tap -- for narrow ``CI``.
+    ``CONV_WGRAD_T`` is the transposed weight gradient ``[KH*KW*CI, CO] = im2col(x)^T @ dy`` in one plane."""
     ex = GemmExtra()
     ex.nb1 = ex.nb2 = 1
     ex.conv = mode
