@@ -27,6 +27,7 @@ them.
 """
 from __future__ import annotations
 
+import os
 from typing import Sequence
 
 import numpy as np
@@ -43,7 +44,13 @@ def _assign(p: torch.Tensor, a: np.ndarray, what: str) -> None:
     if tuple(a.shape) != tuple(p.shape):
         raise ValueError(f"{what}: expected shape {tuple(p.shape)}, got {tuple(a.shape)}")
     with torch.no_grad():
-        p.copy_(torch.from_numpy(a).to(p.dtype))
+        src = torch.from_numpy(a)
+        p.copy_(src.to(p.dtype))
+        # a bf16 parameter that lives in a strategy's flat arenas is a view of the bf16 shadow; the optimizer's
+        # source of truth is its fp32 master slice (engine/flat.py), which takes the unrounded value
+        master = getattr(p, "_dtf_master", None)
+        if master is not None:
+            master.copy_(src.to(master.dtype))
 
 
 def _leaf_export(m: nn.Module) -> list[np.ndarray] | None:
@@ -164,6 +171,18 @@ def set_weights(module: nn.Module, weights: Sequence[np.ndarray]) -> None:
         i += k
     if i != len(ws):
         raise ValueError(f"set_weights: model takes {i} arrays, {len(ws)} were given")
+    sync_masters(module)
+
+
+def sync_masters(module: nn.Module) -> None:
+    """After a write to the parameters of a model whose bf16 parameters are views of a strategy's shadow arena:
+    bring the fp32 master slices (the optimizer's source of truth) in line, so that the next optimizer step does
+    not undo the write. Slices that :func:`_assign` already wrote at full precision are left alone."""
+    with torch.no_grad():
+        for p in module.parameters():
+            master = getattr(p, "_dtf_master", None)
+            if master is not None and not torch.equal(master.to(p.dtype), p.data):
+                master.copy_(p.data.to(master.dtype))
 
 
 def save_weights(module: nn.Module, path: str) -> None:
@@ -188,7 +207,12 @@ def save_weights(module: nn.Module, path: str) -> None:
         return
     arrays = {f"weight_{i:03d}": a for i, (_, a) in enumerate(nw)}
     arrays["names"] = np.array([n for n, _ in nw])
-    np.savez(path, **arrays)
+    if not path.endswith(".npz"):
+        path += ".npz"
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:       # written beside the target and renamed: a crash never leaves a torn file
+        np.savez(f, **arrays)
+    os.replace(tmp, path)
 
 
 def load_weight_list(path: str) -> list[np.ndarray]:
@@ -206,7 +230,7 @@ def load_weight_list(path: str) -> list[np.ndarray]:
                     out.append(np.asarray(lg[wn.decode() if isinstance(wn, bytes) else wn]))
         return out
     with np.load(path if path.endswith(".npz") else path + ".npz", allow_pickle=False) as z:
-        keys = sorted(k for k in z.files if k.startswith("weight_"))
+        keys = sorted((k for k in z.files if k.startswith("weight_")), key=lambda k: int(k.split("_", 1)[1]))
         return [z[k] for k in keys]
 
 

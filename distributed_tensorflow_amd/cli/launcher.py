@@ -87,7 +87,22 @@ def build_parser() -> argparse.ArgumentParser:
                    help="capture the train step into a hipGraph (GPU; keras and collective sync strategies)")
     p.add_argument("--verify-replicas", type=int, default=0, metavar="N",
                    help="debug: every N steps compare the master-weight checksum across ranks (synchronous strategies)")
-    p.add_argument("--fault-inject", default=None, help="RANK:STEP -- kill that worker at that step (testing)")
+    p.add_argument("--fault-inject", default=None,
+                   help="RANK:STEP -- kill that worker at that step; RANK:STEP:hang -- make it stall there (testing)")
+    p.add_argument("--checkpoint-dir", default=None,
+                   help="directory of the run's checkpoint (weights, optimizer state per rank, RNG state, step)")
+    p.add_argument("--checkpoint-every", type=int, default=0, metavar="N",
+                   help="write the checkpoint every N steps (it is always written at the end of training)")
+    p.add_argument("--resume", action="store_true", help="continue from the checkpoint in --checkpoint-dir")
+    p.add_argument("--save-weights", default=None, metavar="PATH",
+                   help="after training write the model as a Keras-ordered weight list (.npz, or .h5 with h5py)")
+    p.add_argument("--load-weights", default=None, metavar="PATH",
+                   help="initialise the model from a Keras-ordered weight list before training")
+    p.add_argument("--supervisor-address", default=None,
+                   help="host of a supervisor listening on port 4000 for 'start' / 'done' / ('results', acc) frames")
+    p.add_argument("--watchdog-s", type=float, default=0.0, metavar="SECONDS",
+                   help="abort a rank (exit code 19) that makes no training progress for this long; 0 = off")
+    p.add_argument("--comm-timeout-s", type=float, default=300.0, help="timeout of every collective / rendezvous")
     return p
 
 
@@ -111,18 +126,16 @@ def _device_for(local_rank: int, want: str) -> torch.device:
 def _fault_hook(spec: str | None):
     if not spec:
         return None
-    rank, step = (int(v) for v in spec.split(":"))
+    parts = spec.split(":")
+    rank, step = int(parts[0]), int(parts[1])
+    hang = len(parts) > 2 and parts[2] == "hang"
 
     def hook(r, s):
         if r == rank and s == step:
+            if hang:
+                time.sleep(3600)
             os._exit(17)
     return hook
-
-
-def _free_port() -> int:
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 def _train_config(args, centralized: bool, shard_ways: int = 1):
@@ -134,7 +147,7 @@ def _train_config(args, centralized: bool, shard_ways: int = 1):
 
 
 # ----------------------------------------------------------------------------- rank bodies
-def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: str, port: int, queue) -> None:
+def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: str, port, queue) -> None:
     """One rank of a collective (RCCL / gloo) strategy."""
     try:
         from ..comm.backend import Comm
@@ -149,9 +162,16 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
         dev = _device_for(rank, args.device)
         if dev.type == "cuda":
             torch.cuda.set_device(dev)
-        comm = Comm.init(rank, world, dev, getattr(args, "master_addr", None) or "127.0.0.1", port)
+        from ..comm.watchdog import Watchdog, configure_async_errors
+        from ..obs.metrics import SupervisorSink
+        configure_async_errors()
+        # ``port`` is the launcher's shared cell: rank 0 binds an ephemeral rendezvous port and publishes it there
+        comm = Comm.init(rank, world, dev, getattr(args, "master_addr", None) or "127.0.0.1", 0,
+                         timeout_s=float(getattr(args, "comm_timeout_s", 300.0) or 300.0), port_cell=port)
         metrics = MetricsLogger(args.metrics, rank=rank)
+        sup = SupervisorSink(getattr(args, "supervisor_address", None))
         cfg = _train_config(args, centralized=kind in ("sync", "async"))
+        torch.manual_seed(args.seed)          # the initial weights are a function of --seed
         model = model_fn()
         if kind == "keras":
             st = mirrored.MirroredStrategy(model, comm, cfg, metrics=metrics)
@@ -165,6 +185,12 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
             st = ps.AsyncPSStrategy(model, comm, cfg, metrics=metrics, placement=args.placement)
         else:
             raise ValueError(kind)
+        if getattr(args, "load_weights", None):
+            st.replica.model.load_weights(args.load_weights)      # every rank reads the same file
+            st.flat.refresh_shadow()
+        wd_s = float(getattr(args, "watchdog_s", 0.0) or 0.0)
+        if wd_s > 0:
+            st.watchdog = Watchdog(wd_s, rank=rank, poll=getattr(comm, "async_error", None))
         n_workers = world - 1 if dedicated else world
         widx = rank - 1 if dedicated else rank
         reshape = kind in ("sync", "async")  # the reference reshapes to NHWC only in the PS path
@@ -174,9 +200,20 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
                                        index=widx, reshape=reshape)
         else:
             train_ds = None
+        sup.send("start")             # reference dist_keras.py:34-39, server.py:155-158
         if train_ds is not None or dedicated:
             res = st.run_epochs(train_ds, epochs=args.epochs, verbose=1, max_steps=args.max_steps,
-                                fault_hook=_fault_hook(args.fault_inject))
+                                fault_hook=_fault_hook(args.fault_inject),
+                                checkpoint_dir=getattr(args, "checkpoint_dir", None),
+                                checkpoint_every=int(getattr(args, "checkpoint_every", 0) or 0),
+                                resume=bool(getattr(args, "resume", False)))
+        if st.watchdog is not None:
+            st.watchdog.pause()
+        if getattr(args, "save_weights", None) and rank == 0:
+            st.replica.model.save_weights(args.save_weights)
+        # the mirrored worker reports 'done', the parameter server ('done', elapsed)
+        # (reference dist_keras.py:45-47, server.py:121-124)
+        sup.send(["done", res.get("elapsed")] if kind in ("sync", "async") else "done")
         if kind in ("sync", "async"):
             # the parameter server evaluates the unsharded test split (reference server.py:176-180)
             acc = None
@@ -196,6 +233,11 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
             _, acc = st.evaluate(test_ds, reduce=True)
             print("eval: " + str(acc), flush=True)
             res["test_accuracy"] = acc
+        if res.get("test_accuracy") is not None:
+            sup.send(["results", res["test_accuracy"]])        # reference dist_keras.py:56-58, server.py:182-187
+        sup.close()
+        if st.watchdog is not None:
+            st.watchdog.close()
         metrics.summary(strategy=kind, **{k: v for k, v in res.items() if not isinstance(v, torch.Tensor)})
         metrics.close()
         comm.barrier()
@@ -277,7 +319,7 @@ def _join_all(procs, queue, timeout: float | None = None) -> dict:
 def _spawn_collective(args, model_fn, dataset_fn, kind: str, world: int) -> dict:
     ctx = mp.get_context("spawn")
     queue = ctx.Queue()
-    port = _free_port()
+    port = ctx.Value("i", 0)
     procs = [ctx.Process(target=_collective_rank, args=(r, world, args, model_fn, dataset_fn, kind, port, queue))
              for r in range(world)]
     for p in procs:

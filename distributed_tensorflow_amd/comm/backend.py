@@ -36,6 +36,32 @@ class _StagedWork:
         self.works, self.copies = [], []
 
 
+def _published_port(cell, rank: int, port: int | None, timeout_s: float) -> int:
+    """Rank 0 (with ``port``) writes the port it bound into the shared cell; everyone else polls for it. With the
+    framework's own RCCL binding, whose rendezvous listens on a given port, rank 0 reserves one by binding and
+    keeps the socket until its listener is up (``SO_REUSEADDR`` lets the listener take it over)."""
+    import time
+    if rank == 0:
+        if port is None:
+            import socket
+            s = socket.socket()
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            s.bind(("", 0))
+            port = s.getsockname()[1]
+            _held_sockets.append(s)
+        cell.value = int(port)
+        return int(port)
+    t_end = time.time() + timeout_s
+    while cell.value == 0:
+        if time.time() > t_end:
+            raise TimeoutError("rank 0 did not publish the rendezvous port")
+        time.sleep(0.01)
+    return int(cell.value)
+
+
+_held_sockets: list = []
+
+
 class Comm:
     def __init__(self, rank: int = 0, world: int = 1, device: torch.device | str = "cpu", group=None,
                  backend: str | None = None):
@@ -50,12 +76,18 @@ class Comm:
     # ------------------------------------------------------------------ setup
     @classmethod
     def init(cls, rank: int, world: int, device: torch.device | str, master_addr: str = "127.0.0.1",
-             master_port: int = 29500, timeout_s: float = 300.0, backend: str | None = None) -> "Comm":
+             master_port: int = 29500, timeout_s: float = 300.0, backend: str | None = None,
+             port_cell=None) -> "Comm":
+        """``port_cell`` (a ``multiprocessing.Value('i')`` shared by the ranks of one launcher, initially 0):
+        rank 0 binds the rendezvous store to a port the operating system picks and publishes it there; the other
+        ranks wait for it. No port is chosen before it is bound, so two jobs on one host cannot collide on it."""
         device = torch.device(device)
         if world == 1:
             return cls(0, 1, device)
         if backend is None:
             backend = os.environ.get("DTF_COMM") or ("nccl" if device.type == "cuda" else "gloo")
+        if port_cell is not None and backend == "rccl":
+            master_port = _published_port(port_cell, rank, None, timeout_s)
         if backend == "rccl":       # the framework's own RCCL binding instead of torch.distributed
             from .rccl import RcclComm
             return RcclComm.create(rank, world, device, master_addr, master_port, timeout_s)
@@ -64,8 +96,18 @@ class Comm:
             kw = {}
             if backend == "nccl":
                 kw["device_id"] = device
-            dist.init_process_group(backend, init_method=f"tcp://{master_addr}:{master_port}", rank=rank,
-                                    world_size=world, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+            to = datetime.timedelta(seconds=timeout_s)
+            if port_cell is not None:
+                if rank == 0:
+                    store = dist.TCPStore(master_addr, 0, world, True, to, wait_for_workers=False)
+                    _published_port(port_cell, 0, store.port, timeout_s)
+                else:
+                    store = dist.TCPStore(master_addr, _published_port(port_cell, rank, None, timeout_s), world,
+                                          False, to)
+                dist.init_process_group(backend, store=store, rank=rank, world_size=world, timeout=to, **kw)
+            else:
+                dist.init_process_group(backend, init_method=f"tcp://{master_addr}:{master_port}", rank=rank,
+                                        world_size=world, timeout=to, **kw)
         return cls(rank, world, device, backend=backend)
 
     @classmethod

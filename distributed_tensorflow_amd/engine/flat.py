@@ -100,6 +100,7 @@ class FlatParams:
                     sview = self._view(self.shadow, s)
                     sview.copy_(s.param.detach())
                     s.param.data = sview
+                    s.param._dtf_master = mview     # api/keras_weights.py writes loaded weights here too
 
     @classmethod
     def from_module(cls, module: torch.nn.Module, **kw) -> "FlatParams":

@@ -103,9 +103,12 @@ class FlatOptimizer:
         raise ValueError(f"range [{a}, {b}) is not owned by this optimizer instance")
 
     @torch.no_grad()
-    def step(self, ranges: Sequence[tuple[int, int]] | None = None, grad: torch.Tensor | None = None) -> None:
+    def step(self, ranges: Sequence[tuple[int, int]] | None = None, grad: torch.Tensor | None = None,
+             params=None) -> None:
         """One optimizer step over ``ranges`` (default: everything owned). ``grad`` overrides the
-        arena the gradients are read from (same indexing as ``flat.grad``)."""
+        arena the gradients are read from (same indexing as ``flat.grad``). ``params`` overrides the fp32
+        arena that is updated (same indexing as ``flat.master``; the bf16 shadow is then left alone): a
+        parameter-server owner keeps its authoritative shard apart from the replica's working copy."""
         f = self.flat
         g_arena = f.grad if grad is None else grad
         self.hyper.tick()
@@ -115,9 +118,9 @@ class FlatOptimizer:
                 continue
             o = self._locate(a, b)
             n = b - a
-            p = f.master[a:b]
+            p = f.master[a:b] if params is None else params[a:b]
             g = g_arena[a:b]
-            sh = f.shadow[a:b] if f.shadow is not None else None
+            sh = f.shadow[a:b] if (f.shadow is not None and params is None) else None
             if self.spec.kind == "adam":
                 K.adam_apply(p, g, self.m[o:o + n], self.v[o:o + n], self.hyper, shadow=sh, mode=self.mode)
             else:

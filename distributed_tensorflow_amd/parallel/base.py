@@ -12,6 +12,7 @@ between the first step and the last, the quantity the reference prints as
 """
 from __future__ import annotations
 
+import os
 import time
 
 import torch
@@ -21,6 +22,7 @@ from ..comm.backend import Comm
 from ..engine.optimizer import FlatOptimizer
 from ..engine.replica import Replica, TrainConfig
 from ..obs.metrics import MetricsLogger
+from ..obs.trace import PhaseTimer
 
 
 class ReplicaDivergence(RuntimeError):
@@ -44,6 +46,8 @@ class Strategy:
         self.metrics = metrics or MetricsLogger(None, rank=comm.rank)
         self.optimizer: FlatOptimizer | None = None
         self._side_stream = None
+        self.watchdog = None            # comm.watchdog.Watchdog, set by the launcher
+        self.phase_ms: dict[str, float] = {}   # per-phase device time of the last run_epochs (ms per step)
         # row-sharded embedding tables are parameter-server state outside the dense arenas
         from .sharded_embedding import ShardedEmbedding
         self.sparse_modules = [m for m in self.replica.model.modules() if isinstance(m, ShardedEmbedding)]
@@ -113,40 +117,101 @@ class Strategy:
             return n_local
         return int(self.comm.all_reduce_scalar(float(n_local), op=dist.ReduceOp.MIN))
 
+    def _beat(self, what: str) -> None:
+        if self.watchdog is not None:
+            self.watchdog.beat(what)
+
+    def save_checkpoint(self, directory: str, step: int) -> None:
+        from ..utils.checkpoint import save_checkpoint
+        if self.watchdog is not None:
+            self.watchdog.pause()
+        save_checkpoint(directory, self, step=step)
+        if self.watchdog is not None:
+            self.watchdog.resume()
+
+    def try_resume(self, directory: str | None) -> int:
+        """Loads the checkpoint in ``directory`` if there is one; returns the number of steps it had completed."""
+        if not directory or not os.path.exists(os.path.join(directory, "model.pt")):
+            return 0
+        from ..utils.checkpoint import load_checkpoint
+        return load_checkpoint(directory, self)
+
     def run_epochs(self, dataset, epochs: int = 1, verbose: int = 0, max_steps: int | None = None,
-                   fault_hook=None) -> dict:
+                   fault_hook=None, checkpoint_dir: str | None = None, checkpoint_every: int = 0,
+                   resume: bool = False, phase_times: bool | None = None) -> dict:
+        """``checkpoint_dir`` + ``checkpoint_every=N``: a checkpoint after every N completed steps and at the end;
+        ``resume``: continue from the checkpoint in ``checkpoint_dir`` -- the batches of the steps it had completed
+        are skipped, so the run continues with the batch the interrupted one would have seen next.
+        ``phase_times`` (default: when a metrics file is open and the step is not graph-captured): bracket the
+        phases of every step with device events; their per-step averages land in ``self.phase_ms``, the result
+        and the metrics log."""
         dev = self.comm.device
         steps_per_epoch = self.agree_on_steps(dataset.num_batches())
         if max_steps is not None:
             steps_per_epoch = min(steps_per_epoch, max_steps)
+        start = self.try_resume(checkpoint_dir) if resume else 0
         it_count = 0
         last_loss = None
         step = self.step_callable()
+        if phase_times is None:
+            phase_times = self.metrics.enabled
+        timer = PhaseTimer(dev) if (phase_times and not (self.cfg.graph and dev.type == "cuda")) else None
         self.sync_device()
         self.comm.barrier()
+        self._beat("first step")
         t0 = time.time()
-        for ep in range(epochs):
-            it = dataset.iterate(dev)
-            for i in range(steps_per_epoch):
-                batch = next(it)
-                x, y = (batch[0] if len(batch) == 2 else tuple(batch[:-1])), batch[-1]
-                if fault_hook is not None:
-                    fault_hook(self.comm.rank, it_count)
-                ts = time.time()
-                last_loss = step(x, y)
-                if verbose and it_count % 50 == 0 and self.comm.rank == 0:
-                    print(it_count, flush=True)
-                if self.metrics.enabled:
-                    self.metrics.log(step=it_count, epoch=ep, loss=float(last_loss), step_s=time.time() - ts,
-                                     examples=int(y.shape[0]))
-                it_count += 1
-                if self.cfg.verify_replicas and it_count % self.cfg.verify_replicas == 0:
-                    self.check_replicas(it_count)
+        if timer is not None:
+            timer.__enter__()
+        try:
+            for ep in range(epochs):
+                if (ep + 1) * steps_per_epoch <= start:      # an epoch the checkpoint had completed
+                    it_count += steps_per_epoch
+                    continue
+                if hasattr(dataset, "_epoch"):
+                    dataset._epoch = ep                      # the shuffle order is a function of (seed, epoch)
+                it = dataset.iterate(dev)
+                for i in range(steps_per_epoch):
+                    batch = next(it)
+                    if it_count < start:
+                        it_count += 1
+                        continue
+                    x, y = (batch[0] if len(batch) == 2 else tuple(batch[:-1])), batch[-1]
+                    if fault_hook is not None:
+                        fault_hook(self.comm.rank, it_count)
+                    ts = time.time()
+                    last_loss = step(x, y)
+                    if verbose and it_count % 50 == 0 and self.comm.rank == 0:
+                        print(it_count, flush=True)
+                    if self.metrics.enabled:
+                        self.metrics.log(step=it_count, epoch=ep, loss=float(last_loss), step_s=time.time() - ts,
+                                         examples=int(y.shape[0]))
+                    it_count += 1
+                    self._beat(f"step {it_count}")
+                    if self.cfg.verify_replicas and it_count % self.cfg.verify_replicas == 0:
+                        self.check_replicas(it_count)
+                    if checkpoint_dir and checkpoint_every and it_count % checkpoint_every == 0:
+                        self.save_checkpoint(checkpoint_dir, it_count)
+                    if timer is not None and it_count % 50 == 0:
+                        self.metrics.log(event="phases", step=it_count, phase_ms=timer.report())
+        finally:
+            if timer is not None:
+                timer.__exit__(None, None, None)
         self.finalize()
         self.sync_device()
         self.comm.barrier()
         elapsed = time.time() - t0
-        return {"elapsed": elapsed, "steps": it_count, "loss": float(last_loss) if last_loss is not None else None}
+        res = {"elapsed": elapsed, "steps": it_count, "loss": float(last_loss) if last_loss is not None else None,
+               "resumed_from": start}
+        if timer is not None:
+            self.phase_ms = timer.report()
+            res["phase_ms"] = self.phase_ms
+            if self.phase_ms and it_count > start:
+                step_ms = elapsed * 1e3 / (it_count - start)
+                res["exposed_comm_fraction"] = sum(v for k, v in self.phase_ms.items()
+                                                   if k in ("grad_sync_wait", "push_wait", "pull")) / step_ms
+        if checkpoint_dir:
+            self.save_checkpoint(checkpoint_dir, it_count)
+        return res
 
     # ------------------------------------------------------------ helpers
     def side_stream(self):

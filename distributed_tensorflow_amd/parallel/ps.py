@@ -17,15 +17,15 @@ Here the server state -- fp32 master parameters and optimizer moments -- is
 
 ``async``  no barrier between workers: a worker pushes its gradient shard to
            each owner and receives that owner's current parameters; an owner
-           applies each arriving gradient immediately on a side stream, under
-           a lock that plays the part of ``model_lock`` (server.py:99-102).
-           Each (owner, worker) pair has its own 2-rank communicator and a
-           host service thread, because arrival order is data dependent.
+           applies each arriving gradient immediately (server.py:99-102). See
+           :class:`AsyncPSStrategy` for the stream / event / thread design.
            The dedicated topology of the reference (one extra server process,
            ``-n`` workers) is ``placement='dedicated'``.
 """
 from __future__ import annotations
 
+import os
+import socket
 import threading
 import time
 
@@ -133,21 +133,74 @@ class _Shifted:
 
 
 # ============================================================================ async
-_CMD_TRAIN, _CMD_END = 1, 2
+_K_HELLO, _K_TRAIN, _K_REPLY, _K_END = 1, 2, 3, 4
+
+# Host-side serialisation of RCCL calls. A process drives several two-rank communicators here (one per
+# owner/worker pair) from its training thread and its service threads; RCCL gives no ordering guarantee for
+# calls that race on different communicators of one process, so every call is made under this lock: from
+# RCCL's point of view one thread issues them all, one after the other. A call only ENQUEUES work (kernels on
+# the communicator's stream; completion is a stream dependency, never a host wait), so the lock is held for
+# microseconds; the connections are set up beforehand, in one global order, where the first call on a
+# communicator does block on its peer. gloo calls block until they are matched and must not share a lock.
+_RCCL_CALLS = threading.Lock()
+
+
+class _NoLock:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def _host_address(master_addr: str | None) -> str:
+    """The address other ranks reach this one at (control connections of the asynchronous server)."""
+    env = os.environ.get("DTF_HOST_ADDR")
+    if env:
+        return env
+    if master_addr in (None, "", "127.0.0.1", "localhost"):
+        return "127.0.0.1"
+    try:
+        return socket.gethostbyname(socket.gethostname())
+    except OSError:
+        return "127.0.0.1"
 
 
 class AsyncPSStrategy(Strategy):
-    """Asynchronous parameter server over per-pair communicators.
+    """Asynchronous parameter server with device-resident shards.
 
     ``placement='colocated'``: every rank is a worker and owns shard r of the arena.
     ``placement='dedicated'``: rank 0 is the server (owns everything, does not train), ranks
     1..W-1 are the workers -- the process layout of the reference launcher
     (reference initializer.py:134-145).
+
+    Roles are kept apart as in the reference, where the server owns the model and every client a copy
+    (reference centralized/server.py:148-150, client.py:65,72): an owner's authoritative shard (``ps_master``
+    and the optimizer moments) is separate memory from the replica's working parameters (``flat.master``), which
+    only the training thread writes -- by its pulls.
+
+    Control plane: one framed-TCP connection per (owner, worker) pair and, on the owner, one host thread per
+    worker blocked in a socket read -- the reference's thread-per-connection server (server.py:168-174). A push
+    is ANNOUNCED there (``train``, the parameter version the gradient was computed on) and answered there (the
+    version after the apply): versions and staleness are host integers, and no thread ever parks a receive
+    kernel on the GPU or reads a device tensor back to learn what to do next.
+
+    Data plane: one two-rank communicator per ordered (owner, worker) pair (RCCL send/recv over the pair's own
+    xGMI link; gloo on CPU). The worker posts its gradient shards and its parameter receives to ALL owners
+    before it waits for anything, so the seven links of a GPU work at once.
+
+    ``model_lock`` (server.py:99-102) is an event chain on ONE apply stream per owner. Every apply -- a remote
+    worker's and, colocated, the owner's own -- is enqueued on that stream, under a host lock that only fixes
+    the enqueue order: receive of the gradient (the stream waits for its arrival) -> fused optimizer kernel on
+    the owner's shard -> copy of the updated shard into that worker's reply buffer -> send (which waits for the
+    copy). Two applies can therefore never overlap on the device, a reply is a snapshot between two applies, and
+    nothing is lost; the training stream joins the chain through a "gradient ready" event before its own apply
+    and an "applied" event after it.
     """
     name = "async"
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None, metrics=None,
-                 placement: str = "colocated", max_staleness: int | None = None):
+                 placement: str = "colocated", max_staleness: int | None = None, master_addr: str | None = None):
         cfg = cfg or TrainConfig()
         if placement not in ("colocated", "dedicated"):
             raise ValueError("placement must be 'colocated' or 'dedicated'")
@@ -158,6 +211,7 @@ class AsyncPSStrategy(Strategy):
         cfg.shard_ways = max(cfg.shard_ways, len(self.servers))
         super().__init__(model, comm, cfg, optimizer, metrics)
         r = comm.rank
+        dev = comm.device
         S = len(self.servers)
         n = self.flat.total // S
         self.shard_of = {s: (i * n, (i + 1) * n) for i, s in enumerate(self.servers)}
@@ -165,66 +219,137 @@ class AsyncPSStrategy(Strategy):
         self.is_worker = r in self.workers
         self.max_staleness = max_staleness
         self.broadcast_initial(0)
-        # one 2-rank communicator per ordered (server, worker) pair; creation is collective
-        self.pair: dict[tuple[int, int], Comm] = {}
-        if W > 1:
-            for s in self.servers:
-                for w in self.workers:
-                    if s != w:
-                        c = comm.subgroup([s, w])
-                        if r in (s, w):
-                            self.pair[(s, w)] = c
-        self.lock = threading.Lock()          # the reference's model_lock
-        self.version = 0                      # number of gradient applications on this shard
+        self.lock = threading.Lock()          # the reference's model_lock: fixes the enqueue order of applies
+        self.version = 0                      # gradient applications enqueued on this shard so far
         self.staleness_log: list[int] = []
         self._threads: list[threading.Thread] = []
         self._errors: list[BaseException] = []
+        self._versions_seen = {s: 0 for s in self.servers}
+        self._apply_stream = torch.cuda.Stream(dev) if dev.type == "cuda" else None
+        self._calls = _RCCL_CALLS if comm.backend == "nccl" else _NoLock()
+        self.pair: dict[tuple[int, int], Comm] = {}
+        self._ctrl: dict[int, object] = {}    # worker side: owner rank -> control connection
+        self.ps_master = None
         if self.is_server:
             a, e = self.shard_of[r]
+            self.ps_master = self.flat.master[a:e].clone()     # the authoritative shard
             self.optimizer = FlatOptimizer(self.flat, optimizer, state_ranges=[(a, e)])
-            self._apply_stream = self.side_stream()
-            for w in self.workers:
-                if w != r:
-                    t = threading.Thread(target=self._serve, args=(w,), daemon=True, name=f"ps-serve-{w}")
-                    t.start()
-                    self._threads.append(t)
-        self._versions_seen = {s: 0 for s in self.servers}
+        if W > 1:
+            self._connect(master_addr)
+
+    # ---------------------------------------------------------------- set-up
+    def _connect(self, master_addr) -> None:
+        from ..comm import tcp
+        comm, r, dev = self.comm, self.comm.rank, self.comm.device
+        W = comm.world
+        pairs = [(s, w) for s in self.servers for w in self.workers if s != w]
+        # data plane: creation is collective on the parent group, in one order on every rank
+        for s, w in pairs:
+            c = comm.subgroup([s, w])
+            if r in (s, w):
+                self.pair[(s, w)] = c
+        # control plane: owners listen on an ephemeral port; (address, port) travel by all-gather
+        listener = None
+        port = 0
+        if self.is_server and any(w != r for w in self.workers):
+            addr = _host_address(master_addr)
+            listener = tcp.Listener("127.0.0.1" if addr == "127.0.0.1" else "0.0.0.0", 0)
+            port = listener.port
+        ip = [int(v) for v in _host_address(master_addr).split(".")]
+        mine = torch.tensor(ip + [port], dtype=torch.int64, device=dev)
+        table = torch.zeros(W * 5, dtype=torch.int64, device=dev)
+        comm.all_gather(table, mine)
+        table = table.cpu().reshape(W, 5).tolist()
+        if self.is_worker:
+            for s in self.servers:
+                if s != r:
+                    host = ".".join(str(v) for v in table[s][:4])
+                    c = tcp.connect(host, table[s][4], timeout=120.0, conn_timeout=600.0)
+                    c.send(_K_HELLO, {"rank": r})
+                    self._ctrl[s] = c
+        conns = {}
+        if listener is not None:
+            for _ in [w for w in self.workers if w != r]:
+                c = listener.accept(timeout=120.0, conn_timeout=-1.0)
+                kind, meta, _ = c.recv(timeout=120.0)
+                if kind != _K_HELLO:
+                    raise RuntimeError("asynchronous parameter server: unexpected first control message")
+                conns[int(meta["rank"])] = c
+            listener.close()
+        # first use of a communicator sets its connection up and blocks on the peer: do it here, pair by pair in
+        # the global order, so that later calls only enqueue
+        a0 = torch.zeros(8, dtype=torch.float32, device=dev)
+        for s, w in pairs:
+            if r == s:
+                c = self.pair[(s, w)]
+                c.recv(a0, 1 - c.rank)
+                c.send(a0, 1 - c.rank)
+            elif r == w:
+                c = self.pair[(s, w)]
+                c.send(a0, 1 - c.rank)
+                c.recv(a0, 1 - c.rank)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        for w, c in conns.items():
+            t = threading.Thread(target=self._serve, args=(w, c), daemon=True, name=f"ps-serve-{w}")
+            t.start()
+            self._threads.append(t)
 
     # ---------------------------------------------------------------- server
-    def _apply_locked(self, grad_shard: torch.Tensor, version_used: int) -> int:
-        a, e = self.shard_of[self.comm.rank]
-        with self.lock:
-            self.staleness_log.append(self.version - version_used)
-            self.optimizer.step([(a, e)], grad=_Shifted(grad_shard, -a))
-            self.version += 1
-            return self.version
+    def _stream_ctx(self):
+        return torch.cuda.stream(self._apply_stream) if self._apply_stream is not None else _NoLock()
 
-    def _serve(self, worker: int) -> None:
-        """Service thread for one worker: receive (command, gradient shard), apply, reply with the
-        current parameter shard -- the body of the reference's ``Server.run`` loop."""
+    def _apply(self, grad_shard: torch.Tensor, version_used: int) -> int:
+        """One optimizer step on the authoritative shard; the caller holds ``self.lock`` and has made the apply
+        stream current."""
+        a, e = self.shard_of[self.comm.rank]
+        self.staleness_log.append(self.version - version_used)
+        self.optimizer.step([(a, e)], grad=_Shifted(grad_shard, -a), params=_Shifted(self.ps_master, -a))
+        self.version += 1
+        return self.version
+
+    def _serve(self, worker: int, conn) -> None:
+        """Service thread of one worker: wait for an announcement on the control connection, then enqueue
+        receive -> apply -> reply on the apply stream -- the body of the reference's ``Server.run`` loop
+        (reference centralized/server.py:62-105)."""
         try:
             r = self.comm.rank
             c = self.pair[(r, worker)]
             peer = 1 - c.rank
             a, e = self.shard_of[r]
             dev = self.comm.device
-            ctrl = torch.zeros(2, dtype=torch.int64, device=dev)
             grad = torch.empty(e - a, dtype=self.flat.grad.dtype, device=dev)
             reply = torch.empty(e - a, dtype=torch.float32, device=dev)
-            stream = torch.cuda.Stream(dev) if dev.type == "cuda" else None
+            send_stream = torch.cuda.Stream(dev) if dev.type == "cuda" else None
             while True:
-                with (torch.cuda.stream(stream) if stream is not None else _null()):
-                    c.recv(ctrl, peer)
-                    cmd, used = (int(v) for v in ctrl.tolist())
-                    if cmd == _CMD_END:
-                        break
-                    c.recv(grad, peer)
-                    ver = self._apply_locked(grad, used)
-                    with self.lock:
-                        reply.copy_(self.flat.master[a:e])
-                    ctrl[0], ctrl[1] = _CMD_TRAIN, ver
-                    c.send(ctrl, peer)
-                    c.send(reply, peer)
+                kind, meta, _ = conn.recv()
+                if kind == _K_END:
+                    break
+                if kind != _K_TRAIN:
+                    raise RuntimeError(f"asynchronous parameter server: unknown control message {kind}")
+                copied = None
+                with self.lock, self._stream_ctx():
+                    # the worker posted its send before it announced the push: this wait is bounded
+                    with self._calls:
+                        works = c.exchange([], [(grad, peer)])
+                    for w_ in works:
+                        w_.wait()
+                    ver = self._apply(grad, int(meta["used"]))
+                    reply.copy_(self.ps_master)
+                    if send_stream is not None:
+                        copied = torch.cuda.Event()
+                        copied.record()
+                # the reply leaves outside the lock (its buffer belongs to this thread): a worker that is slow to
+                # take it delays nobody else's apply
+                with (torch.cuda.stream(send_stream) if send_stream is not None else _NoLock()):
+                    if copied is not None:
+                        send_stream.wait_event(copied)
+                    with self._calls:
+                        works = c.exchange([(reply, peer)], [])
+                    for w_ in works:
+                        w_.wait()
+                conn.send(_K_REPLY, {"version": ver})
+            conn.close()
         except BaseException as ex:  # surfaced by join_servers()
             self._errors.append(ex)
 
@@ -232,49 +357,80 @@ class AsyncPSStrategy(Strategy):
     def train_step(self, x, y):
         if not self.is_worker:
             raise RuntimeError("a dedicated server rank does not train; call serve_until_done()")
-        f = self.flat
-        r = self.comm.rank
         loss = self.replica.forward_backward(x, y, None, 1.0)
         self.replica.finish_backward()
-        dev = self.comm.device
-        for s in self.servers:
-            a, e = self.shard_of[s]
-            if s == r:
-                ver = self._apply_locked(f.grad[a:e], self._versions_seen[s])
-                self._versions_seen[s] = ver
-                continue
-            c = self.pair[(s, r)]
-            peer = 1 - c.rank
-            ctrl = torch.tensor([_CMD_TRAIN, self._versions_seen[s]], dtype=torch.int64, device=dev)
-            c.send(ctrl, peer)
-            c.send(f.grad[a:e], peer)
-            c.recv(ctrl, peer)
-            c.recv(f.master[a:e], peer)
-            self._versions_seen[s] = int(ctrl[1])
-        f.refresh_shadow()
+        self.push_pull()
         return loss
+
+    def push_pull(self) -> None:
+        """Pushes ``flat.grad`` to the shard owners and pulls their parameters into ``flat.master`` -- one
+        iteration of the reference worker's send / receive / ``set_weights`` (reference client.py:85-90)."""
+        f = self.flat
+        r = self.comm.rank
+        dev = self.comm.device
+        remote = [s for s in self.servers if s != r]
+        # post every transfer (gradient out, parameters in; nothing here waits), then announce the pushes: all
+        # owners, and all links, work at once
+        works = []
+        for s in remote:
+            a, e = self.shard_of[s]
+            c = self.pair[(s, r)]
+            with self._calls:
+                works += c.exchange([(f.grad[a:e], 1 - c.rank)], [(f.master[a:e], 1 - c.rank)])
+        for s in remote:
+            self._ctrl[s].send(_K_TRAIN, {"used": self._versions_seen[s]})
+        if r in self.shard_of:
+            # colocated: this rank's own shard goes through the same chain, without a transfer
+            a, e = self.shard_of[r]
+            ready = applied = None
+            if self._apply_stream is not None:
+                ready = torch.cuda.Event()
+                ready.record()
+            with self.lock, self._stream_ctx():
+                if ready is not None:
+                    self._apply_stream.wait_event(ready)
+                self._versions_seen[r] = self._apply(f.grad[a:e], self._versions_seen[r])
+                f.master[a:e].copy_(self.ps_master)
+                if ready is not None:
+                    applied = torch.cuda.Event()
+                    applied.record()
+            if applied is not None:
+                torch.cuda.current_stream(dev).wait_event(applied)
+        for s in remote:
+            kind, meta, _ = self._ctrl[s].recv()
+            if kind != _K_REPLY:
+                raise RuntimeError("asynchronous parameter server: unexpected reply on the control connection")
+            self._versions_seen[s] = int(meta["version"])
+        for w_ in works:
+            w_.wait()
+        f.refresh_shadow()
 
     def finalize(self) -> None:
         r = self.comm.rank
-        dev = self.comm.device
         if self.is_worker:
-            for s in self.servers:
-                if s != r:
-                    c = self.pair[(s, r)]
-                    c.send(torch.tensor([_CMD_END, 0], dtype=torch.int64, device=dev), 1 - c.rank)
+            for s, c in self._ctrl.items():
+                c.send(_K_END, {})
+                c.close()
+            self._ctrl = {}
         self.join_servers()
-        # final model = the servers' shards
+        # final model = the owners' shards
+        if self.ps_master is not None:
+            a, e = self.shard_of[r]
+            if self._apply_stream is not None:
+                torch.cuda.current_stream(self.comm.device).wait_stream(self._apply_stream)
+            self.flat.master[a:e].copy_(self.ps_master)
         if self.comm.world > 1:
             for s in self.servers:
                 a, e = self.shard_of[s]
                 self.comm.broadcast(self.flat.master[a:e], s)
-            self.flat.refresh_shadow()
+        self.flat.refresh_shadow()
 
     def join_servers(self, timeout: float = 600.0) -> None:
         for t in self._threads:
             t.join(timeout)
             if t.is_alive():
                 raise TimeoutError(f"parameter-server thread {t.name} did not finish")
+        self._threads = []
         if self._errors:
             raise RuntimeError(f"parameter-server thread failed: {self._errors[0]!r}") from self._errors[0]
 
@@ -282,41 +438,50 @@ class AsyncPSStrategy(Strategy):
         """Body of a dedicated server rank: wait until every worker has sent ``end``."""
         self.join_servers()
 
-    def run_epochs(self, dataset, epochs: int = 1, verbose: int = 0, max_steps: int | None = None, fault_hook=None):
+    def run_epochs(self, dataset, epochs: int = 1, verbose: int = 0, max_steps: int | None = None, fault_hook=None,
+                   checkpoint_dir: str | None = None, checkpoint_every: int = 0, resume: bool = False,
+                   phase_times: bool | None = None):
+        """Workers do not wait for each other between steps: only start and end are collective. A checkpoint is
+        written at the end (the state of an asynchronous run in flight is not a single point in time)."""
+        if resume:
+            self.try_resume(checkpoint_dir)
+            if self.ps_master is not None:
+                a, e = self.shard_of[self.comm.rank]
+                self.ps_master.copy_(self.flat.master[a:e])
+        it_count, last = 0, None
         if self.is_worker:
-            # async workers do not wait for each other between steps: only start and end are collective
             n_local = dataset.num_batches()
             steps = n_local if max_steps is None else min(n_local, max_steps)
             self.sync_device()
             self.comm.barrier()
+            self._beat("first step")
             t0 = time.time()
-            it_count, last = 0, None
             for ep in range(epochs):
                 it = dataset.iterate(self.comm.device)
                 for _ in range(steps):
                     x, y = next(it)
                     if fault_hook is not None:
                         fault_hook(self.comm.rank, it_count)
+                    ts = time.time()
                     last = self.train_step(x, y)
                     if verbose and it_count % 50 == 0:
                         print(it_count, flush=True)
+                    if self.metrics.enabled:
+                        self.metrics.log(step=it_count, epoch=ep, loss=float(last), step_s=time.time() - ts,
+                                         examples=int(y.shape[0]), version=max(self._versions_seen.values()))
                     it_count += 1
-            self.finalize()
-            self.sync_device()
+                    self._beat(f"step {it_count}")
+        else:
             self.comm.barrier()
-            return {"elapsed": time.time() - t0, "steps": it_count, "loss": float(last) if last is not None else None,
-                    "mean_staleness": (sum(self.staleness_log) / max(1, len(self.staleness_log)))}
-        self.comm.barrier()
-        t0 = time.time()
+            t0 = time.time()
+        if self.watchdog is not None:
+            self.watchdog.pause()        # a finished worker waits for the slowest one below
         self.finalize()
+        self.sync_device()
         self.comm.barrier()
-        return {"elapsed": time.time() - t0, "steps": 0, "loss": None,
-                "mean_staleness": (sum(self.staleness_log) / max(1, len(self.staleness_log)))}
-
-
-class _null:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *a):
-        return False
+        res = {"elapsed": time.time() - t0, "steps": it_count, "loss": float(last) if last is not None else None,
+               "mean_staleness": (sum(self.staleness_log) / max(1, len(self.staleness_log))),
+               "max_staleness": max(self.staleness_log, default=0)}
+        if checkpoint_dir:
+            self.save_checkpoint(checkpoint_dir, it_count)
+        return res

@@ -30,6 +30,30 @@ def _atomic_save(obj, path: str) -> None:
     os.replace(tmp, path)
 
 
+def _rng_state(device) -> dict:
+    """Random-number state that a resumed run must continue from for dropout masks to repeat: torch's CPU (and
+    device) generator and the device-resident Philox offset of the fused dropout kernels."""
+    out = {"cpu": torch.get_rng_state()}
+    if device.type == "cuda":
+        out["cuda"] = torch.cuda.get_rng_state(device)
+        from ..ops import rng as _rng
+        st = _rng._states.get((device.type, device.index))
+        if st is not None:
+            out["philox_seed"] = torch.tensor([st.seed & ((1 << 63) - 1), st.seed >> 63], dtype=torch.int64)
+            out["philox_offset"] = st.offset.detach().cpu()
+    return out
+
+
+def _set_rng_state(state: dict, device) -> None:
+    torch.set_rng_state(state["cpu"])
+    if device.type == "cuda" and "cuda" in state:
+        torch.cuda.set_rng_state(state["cuda"], device)
+        if "philox_offset" in state:
+            from ..ops import rng as _rng
+            st = _rng.state_for(device)
+            st.offset.copy_(state["philox_offset"].to(device))
+
+
 def save_checkpoint(directory: str, strategy, step: int | None = None, keras_export: bool = True) -> None:
     os.makedirs(directory, exist_ok=True)
     comm, flat = strategy.comm, strategy.flat
@@ -45,7 +69,8 @@ def save_checkpoint(directory: str, strategy, step: int | None = None, keras_exp
             kw.save_weights(model, os.path.join(directory, "weights.npz"))
     opts = getattr(strategy, "optimizers", None) or ([strategy.optimizer] if strategy.optimizer is not None else [])
     state = {"optimizers": [o.state_dict() for o in opts],
-             "sparse": [m.state_dict_shard() for m in getattr(strategy, "sparse_modules", [])]}
+             "sparse": [m.state_dict_shard() for m in getattr(strategy, "sparse_modules", [])],
+             "rng": _rng_state(comm.device)}
     _atomic_save(state, os.path.join(directory, f"optim_rank{comm.rank}.pt"))
     comm.barrier()
 
@@ -74,6 +99,8 @@ def load_checkpoint(directory: str, strategy) -> int:
             o.load_state_dict(sd)
         for m, sd in zip(getattr(strategy, "sparse_modules", []), st.get("sparse", [])):
             m.load_state_dict_shard(sd)
+        if "rng" in st:
+            _set_rng_state(st["rng"], comm.device)
     strategy.replica.step_count = int(ck["step"])
     comm.barrier()
     return int(ck["step"])

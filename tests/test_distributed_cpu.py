@@ -301,3 +301,84 @@ def test_verify_replicas_detects_a_diverged_rank_on_every_rank(kind):
     assert _run(_verify_body, 2, kind, False) == ["ok", "ok"]
     out = _run(_verify_body, 2, kind, True)
     assert all(o.startswith("diverged") for o in out), out
+
+
+# --------------------------------------------------------------------------- async PS: no lost update
+def _exact_async_worker(rank, world, cell, q, device, steps):
+    """Pushes integer-valued gradients through the asynchronous parameter server with plain SGD and a power-of-two
+    learning rate: every sum is exact in fp32 whatever the order of the applies, so the final parameters must equal
+    init - lr * (sum of all gradients) bit for bit. A lost or doubled update, or a torn reply, changes them."""
+    import traceback
+    try:
+        from distributed_tensorflow_amd.comm.backend import Comm
+        from distributed_tensorflow_amd.engine.optimizer import SGD
+        from distributed_tensorflow_amd.engine.replica import TrainConfig
+        from distributed_tensorflow_amd.models.mlp import reference_mlp
+        from distributed_tensorflow_amd.parallel import ps
+
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            torch.cuda.set_device(dev)
+        comm = Comm.init(rank, world, dev, timeout_s=120, backend="gloo", port_cell=cell)
+        torch.manual_seed(0)
+        lr = 2.0 ** -10
+        st = ps.AsyncPSStrategy(reference_mlp(dropout=0.0), comm, TrainConfig(seed=0),
+                                optimizer=SGD(learning_rate=lr, momentum=0.0))
+        f = st.flat
+        n = f.total
+        # parameters on a 2^-10 grid, small: every intermediate value is exactly representable
+        init = (torch.arange(n, dtype=torch.float32) % 257 - 128) * lr
+        f.master.copy_(init.to(dev))
+        if st.ps_master is not None:
+            a, e = st.shard_of[rank]
+            st.ps_master.copy_(f.master[a:e])
+        comm.barrier()
+        total = torch.zeros(n, dtype=torch.float32)
+        for r in range(world):
+            for i in range(steps):
+                g = torch.Generator().manual_seed(1000 * r + i)
+                gi = torch.randint(-4, 5, (n,), generator=g).float()
+                total += gi
+                if r == rank:
+                    f.grad.copy_(gi.to(dev))
+                    st.push_pull()
+        st.finalize()
+        st.sync_device()
+        want = init - lr * total
+        got = f.master.cpu()
+        q.put((rank, {"equal": bool(torch.equal(got, want)), "maxdiff": float((got - want).abs().max()),
+                      "applies": len(st.staleness_log), "max_staleness": max(st.staleness_log, default=0)}))
+        comm.barrier()
+        comm.shutdown()
+    except Exception as e:  # pragma: no cover
+        q.put((rank, {"error": f"{e}\n{traceback.format_exc()}"}))
+
+
+def run_exact_async(world, device, steps):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    cell = ctx.Value("i", 0)
+    procs = [ctx.Process(target=_exact_async_worker, args=(r, world, cell, q, device, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        while len(got) < world:
+            r, res = q.get(timeout=240)
+            got[r] = res
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    return got
+
+
+def test_async_ps_loses_no_update_under_concurrent_service_threads():
+    world, steps = 4, 50                      # 3 service threads per owner, 200 applies per shard
+    got = run_exact_async(world, "cpu", steps)
+    for r in range(world):
+        assert "error" not in got[r], got[r].get("error")
+        assert got[r]["applies"] == world * steps
+        assert got[r]["equal"], got[r]

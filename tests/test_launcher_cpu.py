@@ -151,3 +151,113 @@ def test_standalone_role_entry_points_run_a_job_started_by_hand(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in ks]
     assert all(p.returncode == 0 for p in ks), outs
     assert all("eval:" in o for o in outs)
+
+
+def _run_launcher(flags, timeout=300):
+    cmd = [sys.executable, os.path.join(ROOT, "initializer.py"), *flags, "--device", "cpu"]
+    return subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+@pytest.mark.parametrize("mode", ["-m d -ds keras", "-m c -cs sync --transport collective"])
+def test_killed_run_resumes_to_the_same_weights_bit_for_bit(tmp_path, mode):
+    """10 steps uninterrupted == 10 steps with a worker killed at step 7 and a resume from the step-5 checkpoint
+    (weights, optimizer moments, step counter, dropout RNG and data position all continue)."""
+    import numpy as np
+    base = mode.split() + "-n 2 -b 32 --max-steps 10 --checkpoint-every 5".split()
+    a = _run_launcher(base + ["--checkpoint-dir", str(tmp_path / "ckA"), "--save-weights", str(tmp_path / "A.npz")])
+    assert a.returncode == 0, a.stdout[-1500:] + a.stderr[-1500:]
+    b1 = _run_launcher(base + ["--checkpoint-dir", str(tmp_path / "ckB"), "--fault-inject", "0:7",
+                               "--comm-timeout-s", "30"])
+    assert b1.returncode != 0                                  # the job died with its worker
+    assert (tmp_path / "ckB" / "model.pt").exists()
+    b2 = _run_launcher(base + ["--checkpoint-dir", str(tmp_path / "ckB"), "--resume", "--save-weights",
+                               str(tmp_path / "B.npz"), "--results", str(tmp_path / "resB.json")])
+    assert b2.returncode == 0, b2.stdout[-1500:] + b2.stderr[-1500:]
+    res = json.load(open(tmp_path / "resB.json"))
+    assert res["rank0"]["resumed_from"] == 5 and res["rank0"]["steps"] == 10
+    wa, wb = np.load(tmp_path / "A.npz"), np.load(tmp_path / "B.npz")
+    keys = [k for k in wa.files if k.startswith("weight_")]
+    assert keys and set(keys) <= set(wb.files)
+    for k in keys:
+        assert np.array_equal(wa[k], wb[k]), k
+
+
+def test_load_weights_flag_starts_training_from_the_file(tmp_path):
+    import numpy as np
+    a = _run_launcher("-m d -ds keras -n 1 -b 32 --max-steps 3".split() + ["--save-weights", str(tmp_path / "w.npz")])
+    assert a.returncode == 0, a.stderr[-1500:]
+    # zero steps from the loaded file (bf16 arenas: the loaded values must survive in the fp32 master) == the file
+    b = _run_launcher("-m d -ds keras -n 1 -b 32 --max-steps 0 --dtype bf16".split()
+                      + ["--load-weights", str(tmp_path / "w.npz"), "--save-weights", str(tmp_path / "w2.npz")])
+    assert b.returncode == 0, b.stderr[-1500:]
+    w, w2 = np.load(tmp_path / "w.npz"), np.load(tmp_path / "w2.npz")
+    for k in (k for k in w.files if k.startswith("weight_")):
+        np.testing.assert_allclose(w2[k], w[k], rtol=1e-2, atol=1e-3)     # bf16 parameters, exported from the shadow
+
+
+def test_mirrored_workers_report_to_the_supervisor(tmp_path):
+    """'start', 'done' and ('results', accuracy) frames of the keras path (reference dist_keras.py:34-58) arrive at
+    a supervisor listening on port 4000's stand-in."""
+    import socket
+    import struct
+    import threading
+    srv = socket.socket()
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        srv.bind(("127.0.0.1", 4000))
+    except OSError:
+        pytest.skip("port 4000 is taken on this host")
+    srv.listen(8)
+    srv.settimeout(120)
+    frames = []
+
+    def reader(c):
+        buf = b""
+        while True:
+            d = c.recv(65536)
+            if not d:
+                break
+            buf += d
+        while buf:
+            n = struct.unpack(">I", buf[:4])[0]
+            frames.append(json.loads(buf[4:4 + n]))
+            buf = buf[4 + n:]
+
+    def acceptor():
+        ts = []
+        try:
+            for _ in range(2):
+                c, _ = srv.accept()
+                t = threading.Thread(target=reader, args=(c,))
+                t.start()
+                ts.append(t)
+        except OSError:
+            pass
+        for t in ts:
+            t.join(60)
+
+    th = threading.Thread(target=acceptor)
+    th.start()
+    try:
+        p = _run_launcher("-m d -ds keras -n 2 -b 32 --max-steps 4 --supervisor-address 127.0.0.1".split())
+        assert p.returncode == 0, p.stderr[-1500:]
+        th.join(60)
+    finally:
+        srv.close()
+    assert frames.count("start") == 2 and frames.count("done") == 2
+    results = [f for f in frames if isinstance(f, list) and f[0] == "results"]
+    assert len(results) == 2 and all(0.0 <= r[1] <= 1.0 for r in results)
+
+
+def test_watchdog_aborts_a_job_whose_peer_stalls(tmp_path):
+    """A rank that stops (without dying) leaves its peer inside a collective: the watchdog ends that peer with exit
+    code 19 and the launcher reports failure in bounded time."""
+    import time
+    t0 = time.time()
+    p = _run_launcher("-m d -ds keras -n 2 -b 32 --max-steps 20 --fault-inject 1:3:hang --watchdog-s 5".split()
+                      + ["--results", str(tmp_path / "r.json")], timeout=200)
+    assert p.returncode != 0
+    assert time.time() - t0 < 150
+    assert "[watchdog] rank 0" in p.stderr
+    res = json.load(open(tmp_path / "r.json"))
+    assert 19 in res["exit_codes"]
