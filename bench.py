@@ -1,14 +1,22 @@
-"""Headline benchmark: ResNet-50 synchronous data-parallel training throughput (images/sec).
+"""Headline benchmark: synchronous data-parallel training throughput, one process per GPU.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Configuration (the headline one): ResNet-50, synthetic 224x224 images, bf16 compute,
-decentralized keras-style mirrored all-reduce, one process per GPU over RCCL. Weak scaling: the
-per-GPU batch is fixed, the global batch grows with N. A step is forward + backward + bucketed
-gradient all-reduce + optimizer update; nothing is skipped inside the timed region.
-Rank 0 prints one JSON line.
+Default configuration (the headline one): ResNet-50, synthetic 224x224 images, bf16 compute,
+decentralized keras-style mirrored all-reduce over RCCL. Weak scaling: the per-GPU batch is fixed, the
+global batch grows with N. A step is forward + backward + bucketed gradient exchange + optimizer update;
+nothing is skipped inside the timed region.
+
+``--strategy`` runs the same step under any other strategy (``custom:ring``, ``custom:direct``, ``ipc-direct``,
+``graph:2``, ``sync``, ``async``); ``--model bert`` is BERT-base MLM at sequence length 512 (sequences/sec, by
+default under ``custom:ring``: the "custom bucketed all-reduce overlapped with backward" configuration).
+
+Rank 0 prints one JSON line. Besides the throughput it carries evidence of what ran: ``ranks_seen`` (an
+all-reduce of ones over the process group), the communication backend, the bucket plan, a replica checksum
+comparison after the timed loop, and -- from a few extra, untimed steps bracketed with device events --
+per-phase device time with the exposed communication wait as a fraction of the step.
 """
 import argparse
 import json
@@ -30,19 +38,25 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DTF_BENCH_BATCH", "1024")),
-                    help="per-GPU batch (weak scaling: fixed per GPU). 1024 measured 4 %% above 512 on one MI355X: the\n"
-                         "per-layer reduction / finalize kernels are amortised over more work")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="per-GPU batch (weak scaling: fixed per GPU); default 1024 images (ResNet-50: 4 %% above 512\n"
+                         "on one MI355X, the per-layer reduction kernels are amortised over more work) / 64 sequences")
     ap.add_argument("--image", type=int, default=224)
-    ap.add_argument("--bucket-mb", type=int, default=16)
+    ap.add_argument("--seq-len", type=int, default=512)
+    ap.add_argument("--bucket-mb", type=int, default=None, help="gradient bucket size (default 48 MiB)")
     ap.add_argument("--conv1x1", default=None, choices=[None, "auto", "gemm", "library"])
     ap.add_argument("--convkxk", default=None, choices=[None, "auto", "gemm", "library"])
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"], help="cpu is for plumbing tests only")
-    ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--model", default="resnet50", choices=["resnet50", "bert", "bert-tiny"])
+    ap.add_argument("--strategy", default=None,
+                    help="keras | custom[:direct|ring|multiring|tree|oneshot] | ipc[-direct|-oneshot|-ring|-tree] | "
+                         "graph[:degree] | sync | async (default: keras for resnet50, custom:ring for bert)")
+    ap.add_argument("--grad-dtype", default="bf16", choices=["bf16", "fp32"], help="dtype the gradients are exchanged in")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph")
+    ap.add_argument("--phase-steps", type=int, default=3, help="untimed steps after the timed loop that measure per-phase device time (0 = skip)")
     a = ap.parse_args()
 
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and a.device == "gpu":
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started without a launcher: start one rank per GPU as child processes (nothing here has
         # touched the GPU yet) and pass their exit code on
         import socket
@@ -67,6 +81,7 @@ def main() -> int:
 
     from distributed_tensorflow_amd import bench_lib
     from distributed_tensorflow_amd.comm.backend import Comm
+    from distributed_tensorflow_amd.obs.trace import PhaseTimer
     from distributed_tensorflow_amd.ops import _lib, conv
 
     if dev.type == "cuda":
@@ -75,19 +90,43 @@ def main() -> int:
         conv.set_conv1x1_backend(a.conv1x1)
     if a.convkxk:
         conv.set_convkxk_backend(a.convkxk)
-    comm = Comm.from_env(dev, timeout_s=1200.0) if world > 1 else Comm(0, 1, dev)   # the first step holds a one-off algorithm search
-    st = bench_lib.make_resnet50_strategy(comm, bucket_mb=a.bucket_mb)
-    x, y = bench_lib.synthetic_imagenet_batch(a.batch, dev, size=a.image, seed=rank)
+    comm = Comm.from_env(dev, timeout_s=1200.0) if world > 1 else Comm(0, 1, dev)
+    bucket_mb = a.bucket_mb or bench_lib.BUCKET_MB
+    gdt = torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32
+    if a.model == "resnet50":
+        strategy = a.strategy or "keras"
+        batch = a.batch or int(os.environ.get("DTF_BENCH_BATCH", "1024"))
+        st = bench_lib.make_resnet50_strategy(comm, bucket_mb=bucket_mb, grad_dtype=gdt, strategy=strategy)
+        x, y = bench_lib.synthetic_imagenet_batch(batch, dev, size=a.image, seed=rank)
+        metric, unit = "images/sec (whole node) ResNet-50 sync DP", "images/sec"
+        cfg_model = {"model": "resnet50", "image": a.image, "seq_len": None,
+                     "optimizer": "sgd-momentum (fused flat-arena kernel)"}
+    else:
+        from distributed_tensorflow_amd.models.bert import synthetic_mlm_batch
+        strategy = a.strategy or "custom:ring"
+        batch = a.batch or 64
+        size = "base" if a.model == "bert" else "tiny"
+        seq = a.seq_len if size == "base" else min(a.seq_len, 64)
+        st = bench_lib.make_bert_strategy(comm, size, seq, bucket_mb=bucket_mb, grad_dtype=gdt, strategy=strategy)
+        x, y = synthetic_mlm_batch(batch, seq, st.replica.model.vocab, dev, n_pred=min(80, seq // 4), seed=rank)
+        metric, unit = "sequences/sec (whole node) BERT-base MLM seq 512", "sequences/sec"
+        cfg_model = {"model": "bert-base-mlm" if size == "base" else "bert-tiny-mlm", "image": None, "seq_len": seq,
+                     "optimizer": "adam (fused flat-arena kernel)"}
 
     def sync():
         comm.barrier()
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
 
+    # proof of the process group: every rank contributes a one
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
+    comm.all_reduce(ones)
+    ranks_seen = int(round(float(ones)))
+
     st.cfg.graph = bool(a.graph and dev.type == "cuda")
     step = st.step_callable()
-    # untimed priming before the counted warm-up steps: the convolution library's one-off algorithm search, RCCL's
-    # communicator set-up and (with --graph) the eager steps and the capture all happen here, whatever --warmup is
+    # untimed priming before the counted warm-up steps: communicator set-up and (with --graph) the eager steps and
+    # the capture all happen here, whatever --warmup is
     for _ in range(5 if st.cfg.graph else 2):
         step(x, y)
     for _ in range(a.warmup):
@@ -104,18 +143,48 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     loss_v = float(loss)
+
+    # ---- after the timed region: where the time goes, and whether the replicas still agree
+    phase_ms, exposed = {}, None
+    if a.phase_steps > 0 and not st.cfg.graph:
+        with PhaseTimer(dev) as pt:
+            sync()
+            tp = time.perf_counter()
+            for _ in range(a.phase_steps):
+                st.train_step(x, y)
+            sync()
+            step_ms = (time.perf_counter() - tp) * 1e3 / a.phase_steps
+            phase_ms = {k: round(v, 3) for k, v in pt.report().items()}
+        wait = sum(v for k, v in phase_ms.items() if k in ("grad_sync_wait", "push_wait", "pull", "push_pull", "gossip"))
+        exposed = round(wait / step_ms, 4) if step_ms > 0 else None
+    st.finalize()
+    agree = None
+    if st.replicas_agree or strategy.startswith(("graph", "async")):
+        try:
+            saved = st.replicas_agree
+            st.replicas_agree = True       # after finalize() every strategy's replicas hold the same model
+            st.check_replicas(a.steps)
+            st.replicas_agree = saved
+            agree = True
+        except Exception as e:  # ReplicaDivergence on every rank
+            agree = False
+            print(f"rank {rank}: {e}", file=sys.stderr)
+    buckets = [b.numel * st.flat.grad.element_size() for b in st.planner.buckets]
     if rank == 0:
         ms = dt / a.steps * 1e3
-        value = a.batch * world * a.steps / dt
+        value = batch * world * a.steps / dt
         print(json.dumps({
-            "metric": "images/sec (whole node) ResNet-50 sync DP", "value": round(value, 2), "unit": "images/sec",
+            "metric": metric, "value": round(value, 2), "unit": unit,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"model": "resnet50", "global_batch": a.batch * world, "per_gpu_batch": a.batch,
-                       "image": a.image, "seq_len": None, "parallelism": f"dp{world}",
-                       "strategy": "decentralized keras-style mirrored all-reduce (bucketed, overlapped)",
-                       "optimizer": "sgd-momentum (fused flat-arena kernel)", "conv1x1": conv.get_conv1x1_backend(), "convkxk": conv.get_convkxk_backend(),
+            "config": {**cfg_model, "global_batch": batch * world, "per_gpu_batch": batch,
+                       "parallelism": f"dp{world}", "strategy": strategy, "grad_dtype": a.grad_dtype,
+                       "conv1x1": conv.get_conv1x1_backend(), "convkxk": conv.get_convkxk_backend(),
                        "hip_graph": st.cfg.graph},
+            "ranks_seen": ranks_seen, "comm_backend": comm.backend if world > 1 else "none (single rank)",
+            "buckets": {"count": len(buckets), "cap_mib": bucket_mb, "total_mib": round(sum(buckets) / 2 ** 20, 2),
+                        "largest_mib": round(max(buckets) / 2 ** 20, 2)},
+            "phase_ms": phase_ms, "exposed_comm_fraction": exposed, "replicas_agree": agree,
             "final_loss": loss_v,
         }), flush=True)
     comm.shutdown()

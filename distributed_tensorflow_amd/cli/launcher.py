@@ -79,7 +79,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--algorithm", default="auto", help="custom strategy: auto|direct|ring|multiring|tree|oneshot on grouped send/recv, or "
                    "ipc|ipc-direct|ipc-oneshot|ipc-ring|ipc-tree: kernels on HIP IPC mapped peer arenas")
     p.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
-    p.add_argument("--port", type=int, default=6000, help="parameter-server / rendezvous port")
+    p.add_argument("--port", type=int, default=6000,
+                   help="parameter-server port (reference: 6000); 0 = one the operating system picks (single machine)")
     p.add_argument("--metrics", default=None, help="JSONL metrics path (%%r = rank)")
     p.add_argument("--results", default=None, help="write a JSON summary of the run here")
     p.add_argument("--seed", type=int, default=0)
@@ -165,9 +166,12 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
         from ..comm.watchdog import Watchdog, configure_async_errors
         from ..obs.metrics import SupervisorSink
         configure_async_errors()
-        # ``port`` is the launcher's shared cell: rank 0 binds an ephemeral rendezvous port and publishes it there
-        comm = Comm.init(rank, world, dev, getattr(args, "master_addr", None) or "127.0.0.1", 0,
-                         timeout_s=float(getattr(args, "comm_timeout_s", 300.0) or 300.0), port_cell=port)
+        # ``port``: a port number (ranks started by hand, one command each), or the launcher's shared cell -- rank 0
+        # then binds an ephemeral rendezvous port and publishes it there
+        by_hand = isinstance(port, int)
+        comm = Comm.init(rank, world, dev, getattr(args, "master_addr", None) or "127.0.0.1", port if by_hand else 0,
+                         timeout_s=float(getattr(args, "comm_timeout_s", 300.0) or 300.0),
+                         port_cell=None if by_hand else port)
         metrics = MetricsLogger(args.metrics, rank=rank)
         sup = SupervisorSink(getattr(args, "supervisor_address", None))
         cfg = _train_config(args, centralized=kind in ("sync", "async"))
@@ -251,26 +255,28 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
         sys.exit(1)
 
 
-def _tcp_server(args, model_fn, dataset_fn, queue, ready) -> None:
+def _tcp_server(args, model_fn, dataset_fn, queue, ready, cell=None) -> None:
     try:
         from ..parallel import ps_tcp
         dev = _device_for(0, args.device)
         ps_tcp.start(args.centralized_strategy, model_fn, dataset_fn, args.n_nodes, cpu_affinity=args.cpu_affinity,
                      server_address=args.server_address, port=args.port, apply=args.apply, device=dev,
-                     cfg=_train_config(args, True), result_queue=queue, metrics_path=args.metrics, ready_event=ready)
+                     cfg=_train_config(args, True), result_queue=queue, metrics_path=args.metrics, ready_event=ready,
+                     port_cell=cell, supervisor_address=getattr(args, "supervisor_address", None))
     except BaseException:
         traceback.print_exc()
         sys.exit(1)
 
 
-def _tcp_worker(index: int, args, model_fn, dataset_fn, queue) -> None:
+def _tcp_worker(index: int, args, model_fn, dataset_fn, queue, cell=None) -> None:
     try:
         from ..parallel import ps_tcp
         dev = _device_for(index, args.device)
         ps_tcp.train(args.batch_size, model_fn=model_fn, dataset_fn=dataset_fn, num_epochs=args.epochs, index=index,
                      n_nodes=args.n_nodes, cpu_affinity=args.cpu_affinity, server_address=args.server_address,
                      port=args.port, device=dev, cfg=_train_config(args, True), max_steps=args.max_steps,
-                     result_queue=queue, fault_hook=_fault_hook(args.fault_inject), metrics_path=args.metrics)
+                     result_queue=queue, fault_hook=_fault_hook(args.fault_inject), metrics_path=args.metrics,
+                     port_cell=cell)
     except BaseException:
         traceback.print_exc()
         sys.exit(1)
@@ -346,9 +352,11 @@ def run(args, model_fn: Callable, dataset_fn: Callable) -> dict:
             ctx = mp.get_context("spawn")
             queue = ctx.Queue()
             ready = ctx.Event()
-            ps = ctx.Process(target=_tcp_server, args=(args, model_fn, dataset_fn, queue, ready))
+            # --port 0: the server binds a port the operating system picks and publishes it to the workers
+            cell = ctx.Value("i", 0) if args.port == 0 else None
+            ps = ctx.Process(target=_tcp_server, args=(args, model_fn, dataset_fn, queue, ready, cell))
             ps.start()
-            nodes = [ctx.Process(target=_tcp_worker, args=(i, args, model_fn, dataset_fn, queue))
+            nodes = [ctx.Process(target=_tcp_worker, args=(i, args, model_fn, dataset_fn, queue, cell))
                      for i in range(args.n_nodes)]
             for p in nodes:
                 p.start()

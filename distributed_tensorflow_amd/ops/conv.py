@@ -100,9 +100,12 @@ class _ConvFn(torch.autograd.Function):
         alias_mask = None
         token = getattr(ctx, "fork_token", None)
         if token is not None and token.masked_grad is not None:
-            ptr, alias_mask = token.masked_grad
+            handed, version, alias_mask = token.masked_grad
             token.masked_grad = None
-            if g_alias is None or g_alias.data_ptr() != ptr:
+            # the gradient that arrives through the alias must be the very tensor the norm handed over, untouched:
+            # a second consumer of the alias makes autograd sum into a new tensor or in place (version counter)
+            if (g_alias is None or g_alias.data_ptr() != handed.data_ptr() or g_alias._version != version
+                    or g_alias.shape != handed.shape):
                 raise RuntimeError("conv2d_fork: the alias fed a norm-add-ReLU residual AND another consumer; the "
                                    "masked gradient hand-over needs the residual to be its only use "
                                    "(ops.conv.set_bn_stats(False) disables the hand-over)")
@@ -132,7 +135,8 @@ class _ConvFn(torch.autograd.Function):
                 add, g_alias, add_mask = g_alias.permute(0, 2, 3, 1), None, alias_mask
             # x came out of a batch norm: reduce that norm's backward sums over gx while gx is stored
             req, part, bn_grad = ctx.grad_req, None, None
-            if (_bn_grad_stats and req is not None and req.x is not None and stride == 1 and req.x.shape == x.shape
+            if (_bn_grad_stats and req is not None and req.consumers == 1 and req.x is not None and stride == 1
+                    and req.x.shape == x.shape
                     and req.x.dtype == torch.bfloat16 and req.x.is_contiguous(memory_format=torch.channels_last)):
                 part = torch.empty((_gemm.col_stats_rows(N * H * W, C), 2, C), dtype=torch.float32, device=x.device)
                 bn_grad = (req.x, req.stats, req.mask, req.relu)
@@ -143,9 +147,9 @@ class _ConvFn(torch.autograd.Function):
                 ex = _gemm.conv_geom(_gemm.CONV_DGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 _gemm.gemm_raw(_gemm.NN, gy, w, gx, N * H * W, C, KH * KW * K, K, KH * KW * C, C, extra=ex, add=add,
                                col_stats=part, bn_grad=bn_grad, add_mask=add_mask)
-            if part is not None:
-                req.partials, req.dy_ptr = part, gx.data_ptr()
             gx = gx.permute(0, 3, 1, 2)
+            if part is not None:
+                req.hand_over(part, gx)
         if g_alias is not None and ctx.needs_input_grad[0]:
             gx = g_alias if gx is None else gx + g_alias
         if want_w:
@@ -187,7 +191,7 @@ class _ConvForkFn(_ConvFn):
         if gy is None:       # the convolution branch was unused
             tk = ctx.fork_token
             if tk is not None and tk.masked_grad is not None:
-                g_alias, tk.masked_grad = _apply_mask_bits(g_alias, tk.masked_grad[1]), None
+                g_alias, tk.masked_grad = _apply_mask_bits(g_alias, tk.masked_grad[2]), None
             return g_alias, None, None, None, None, None, None, None
         return _ConvFn.backward(ctx, gy, g_alias) + (None,)
 

@@ -36,21 +36,31 @@ class GradStatsRequest:
     """Hand-over between a batch norm and the convolution that consumes its output. The norm's forward fills in
     what its backward reductions need (input, statistics, ReLU mask); the convolution's backward, whose
     data-gradient GEMM produces the very gradient those reductions run over, performs them while it stores that
-    gradient and leaves ``partials`` here together with the address of the gradient they belong to. The norm's
-    backward uses them only if the gradient it receives is that tensor (a single consumer), and otherwise
+    gradient and leaves ``partials`` here together with the gradient they belong to. The norm's
+    backward uses them only if the gradient it receives is that tensor, unchanged: exactly one convolution picked
+    the request up (``consumers``), the address matches, and the tensor's version counter has not moved -- autograd
+    sums the gradients of several consumers either into a new tensor (another address) or in place (another
+    version); the request keeps the tensor alive meanwhile, so its address cannot be reused. Otherwise the norm
     reduces on its own."""
-    __slots__ = ("x", "stats", "mask", "relu", "partials", "dy_ptr")
+    __slots__ = ("x", "stats", "mask", "relu", "partials", "dy_ptr", "dy_ref", "dy_version", "consumers")
 
     def __init__(self):
-        self.x = self.stats = self.mask = self.partials = None
-        self.relu, self.dy_ptr = 0, 0
+        self.x = self.stats = self.mask = self.partials = self.dy_ref = None
+        self.relu, self.dy_ptr, self.dy_version, self.consumers = 0, 0, -1, 0
+
+    def hand_over(self, partials, dy: torch.Tensor) -> None:
+        self.partials, self.dy_ref, self.dy_ptr, self.dy_version = partials, dy, dy.data_ptr(), dy._version
+
+    def matches(self, dy: torch.Tensor) -> bool:
+        return (self.partials is not None and self.consumers == 1 and self.dy_ptr == dy.data_ptr()
+                and self.dy_version == dy._version and self.dy_ref is not None and dy.shape == self.dy_ref.shape)
 
 
 class ForkToken:
     """Marks the alias output of ``ops.conv.conv2d_fork``. When that alias is the residual input of a
     norm-add-ReLU, the norm's backward does not write the masked gradient of the residual branch: it hands the
-    incoming gradient itself to the branch and leaves the ReLU mask here (``masked_grad`` = address of that
-    gradient, mask bytes); the fork's backward, which accumulates the branch gradient in its data-gradient GEMM
+    incoming gradient itself to the branch and leaves the ReLU mask here (``masked_grad`` = that gradient, its
+    version counter, mask bytes); the fork's backward, which accumulates the branch gradient in its data-gradient GEMM
     epilogue anyway, applies the mask there. One pass over the widest activations of the network is saved."""
     __slots__ = ("masked_grad",)
 
@@ -63,8 +73,12 @@ _REQ_ATTR = "_dtf_grad_stats_request"
 
 
 def request_of(t: torch.Tensor):
-    """The :class:`GradStatsRequest` attached to a batch-norm output (None for any other tensor)."""
-    return getattr(t, _REQ_ATTR, None)
+    """The :class:`GradStatsRequest` attached to a batch-norm output (None for any other tensor). Every call is a
+    consumer picking the request up; with more than one the hand-over is off."""
+    req = getattr(t, _REQ_ATTR, None)
+    if req is not None:
+        req.consumers += 1
+    return req
 
 
 class _BNActFn(torch.autograd.Function):
@@ -134,7 +148,7 @@ class _BNActFn(torch.autograd.Function):
         nb = lib.dtf_bn_num_partials(ctypes.c_longlong(M), C)
         ws = _scratch(dev, nb * 2 * C)
         req = ctx.request
-        if req is not None and req.partials is not None and req.dy_ptr == dy.data_ptr():
+        if req is not None and req.matches(dy):
             # the convolution that consumed the output already reduced this very gradient
             part = req.partials
             ws = _scratch(dev, max(nb, 256) * 2 * C)
@@ -149,12 +163,12 @@ class _BNActFn(torch.autograd.Function):
                                 _lib.ptr(dres), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(coef), _lib.ptr(ws),
                                 ctypes.c_longlong(M), C, int(ctx.relu), _lib.stream_ptr(dev))
         if req is not None:
-            req.x = req.stats = req.mask = req.partials = None
+            req.x = req.stats = req.mask = req.partials = req.dy_ref = None
         _lib.check(rc, "bn_bwd")
         if ctx.has_res and ctx.relu == 0:
             dres = dy
         if token is not None:
-            token.masked_grad = (dy.data_ptr(), y)       # y holds the mask bytes saved by the forward pass
+            token.masked_grad = (dy, dy._version, y)     # y holds the mask bytes saved by the forward pass
             dres = dy
         return dx, dgb[0], dgb[1], None, None, None, None, None, dres, None, None
 

@@ -208,7 +208,7 @@ class Strategy:
             if self.phase_ms and it_count > start:
                 step_ms = elapsed * 1e3 / (it_count - start)
                 res["exposed_comm_fraction"] = sum(v for k, v in self.phase_ms.items()
-                                                   if k in ("grad_sync_wait", "push_wait", "pull")) / step_ms
+                                                   if k in ("grad_sync_wait", "push_wait", "pull", "push_pull", "gossip")) / step_ms
         if checkpoint_dir:
             self.save_checkpoint(checkpoint_dir, it_count)
         return res

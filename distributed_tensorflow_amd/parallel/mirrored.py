@@ -109,10 +109,12 @@ class CustomAllReduceStrategy(Strategy):
     def train_step(self, x, y):
         self.used_algorithms.clear()
         loss = self.replica.forward_backward(x, y, self._on_ready if self.comm.world > 1 else None, self._scale)
-        for ev in self.replica.finish_backward():
-            if ev is not None:
-                torch.cuda.current_stream(self.comm.device).wait_event(ev)
-        self.optimizer.step()
+        with phase("grad_sync_wait"):
+            for ev in self.replica.finish_backward():
+                if ev is not None:
+                    torch.cuda.current_stream(self.comm.device).wait_event(ev)
+        with phase("optimizer"):
+            self.optimizer.step()
         return loss
 
 
@@ -164,10 +166,12 @@ class GraphStrategy(Strategy):
     def train_step(self, x, y):
         loss = self.replica.forward_backward(x, y, None, 1.0)
         self.replica.finish_backward()
-        self.optimizer.step()
+        with phase("optimizer"):
+            self.optimizer.step()
         self._steps += 1
         if self._steps % self.gossip_every == 0:
-            self.gossip()
+            with phase("gossip"):
+                self.gossip()
         return loss
 
     def finalize(self) -> None:

@@ -359,7 +359,8 @@ class AsyncPSStrategy(Strategy):
             raise RuntimeError("a dedicated server rank does not train; call serve_until_done()")
         loss = self.replica.forward_backward(x, y, None, 1.0)
         self.replica.finish_backward()
-        self.push_pull()
+        with phase("push_pull"):
+            self.push_pull()
         return loss
 
     def push_pull(self) -> None:

@@ -173,10 +173,13 @@ class _ServiceThread(threading.Thread):
 def start(sync_mode, model_fn, dataset_fn, n_nodes, optimizer=None, supervisor_address=None, cpu_affinity=False,
           server_address="127.0.0.1", port: int = DEFAULT_PORT, apply: str = "reduced", device="cpu",
           cfg: TrainConfig | None = None, barrier_timeout: float = 600.0, accept_timeout: float = 600.0,
-          result_queue=None, metrics_path: str | None = None, evaluate: bool = True, ready_event=None) -> dict:
+          result_queue=None, metrics_path: str | None = None, evaluate: bool = True, ready_event=None,
+          port_cell=None) -> dict:
     """Runs the parameter server until every worker has sent ``end``; then evaluates on the test
     split and prints the reference's two result lines. Signature follows reference
-    centralized/server.py:139-140."""
+    centralized/server.py:139-140. ``port_cell`` (a shared ``multiprocessing.Value('i')``): the port the
+    listener is bound to is published there -- with ``port=0`` the operating system picks it, so two jobs
+    on one host never collide."""
     if sync_mode not in ("sync", "async"):
         raise ValueError("Invalid centralized strategy")
     if cpu_affinity:
@@ -189,6 +192,8 @@ def start(sync_mode, model_fn, dataset_fn, n_nodes, optimizer=None, supervisor_a
     sup = SupervisorSink(supervisor_address)
     sup.send("start")
     listener = tcp.Listener(server_address, port, backlog=50)
+    if port_cell is not None:
+        port_cell.value = int(listener.port)
     if ready_event is not None:
         ready_event.set()
     print("accepting", flush=True)
@@ -237,11 +242,19 @@ def start(sync_mode, model_fn, dataset_fn, n_nodes, optimizer=None, supervisor_a
 def train(batch_size, model_fn=None, dataset_fn=None, num_epochs=1, index=0, n_nodes=0, cpu_affinity=False,
           server_address="127.0.0.1", port: int = DEFAULT_PORT, device="cpu", cfg: TrainConfig | None = None,
           connect_timeout: float = 120.0, io_timeout: float = 600.0, max_steps: int | None = None,
-          result_queue=None, fault_hook=None, metrics_path: str | None = None) -> dict:
-    """A parameter-server worker. Signature follows reference centralized/client.py:45-46."""
+          result_queue=None, fault_hook=None, metrics_path: str | None = None, port_cell=None) -> dict:
+    """A parameter-server worker. Signature follows reference centralized/client.py:45-46. ``port_cell``:
+    wait for the server to publish its port there (see :func:`start`)."""
     if cpu_affinity:
         pin_to_core(index + 1)  # core 0 is the parameter server's
     batch_size = int(batch_size)
+    if port_cell is not None:
+        t_end = time.time() + connect_timeout
+        while port_cell.value == 0:
+            if time.time() > t_end:
+                raise TimeoutError("the parameter server did not publish its port")
+            time.sleep(0.01)
+        port = int(port_cell.value)
     conn = tcp.connect(server_address, port, timeout=connect_timeout, retry_interval=0.2, conn_timeout=io_timeout)
     cfg = cfg or TrainConfig(loss_reduction="sum")
     torch.manual_seed(cfg.seed + 1 + index)

@@ -27,6 +27,10 @@ def _check(line, n):
     assert r["config"]["model"] == "resnet50" and r["config"]["global_batch"] == 2 * n
     assert r["config"]["parallelism"] == f"dp{n}"
     assert r["value"] > 0 and abs(r["value"] - 2 * n / (r["ms_per_step"] / 1e3)) / r["value"] < 0.01
+    for k in ("ranks_seen", "comm_backend", "buckets", "phase_ms", "exposed_comm_fraction", "replicas_agree"):
+        assert k in r, k
+    assert r["ranks_seen"] == n
+    assert r["buckets"]["count"] >= 1 and r["buckets"]["cap_mib"] == 48
     return r
 
 
@@ -50,3 +54,24 @@ def test_bench_two_ranks_under_torchrun_gloo():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                      # only rank 0 prints
     _check(lines[0], 2)
+
+
+@pytest.mark.parametrize("strategy", ["keras", "custom:ring", "custom:direct", "sync", "async", "graph:1"])
+def test_bench_every_strategy_two_ranks(strategy):
+    """The benchmark drives every strategy; the JSON proves that two ranks took part, shows the phases and reports
+    that the replicas agree after the run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu",
+           "--model", "bert-tiny", "--batch", "2", "--steps", "2", "--warmup", "1", "--strategy", strategy]
+    p = subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["ranks_seen"] == 2 and r["n_gpus"] == 2 and r["comm_backend"] == "gloo"
+    assert r["config"]["strategy"] == strategy and r["config"]["model"] == "bert-tiny-mlm"
+    assert r["unit"] == "sequences/sec" and r["value"] > 0
+    assert r["replicas_agree"] is True
+    assert "forward" in r["phase_ms"] and "backward" in r["phase_ms"]
+    if strategy in ("keras", "sync"):
+        assert r["exposed_comm_fraction"] is not None

@@ -2,6 +2,7 @@
 the peer-pointer kernels with virtual ranks, and the HIP-IPC peer group with several processes
 that share the GPU (kernel logic, flags and schedules are exercised without xGMI)."""
 import os
+import sys
 
 import pytest
 import torch
@@ -91,7 +92,7 @@ def _ipc_worker(rank, world, port, q):
 
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        comm = Comm.init(rank, world, dev, master_port=port, timeout_s=60, backend="gloo")
+        comm = Comm.init(rank, world, dev, timeout_s=60, backend="gloo", port_cell=port)
         pg = PeerGroup(comm, barrier_budget_ms=10000)
         torch.manual_seed(100 + rank)
         arena = torch.randn(300000, device=dev)
@@ -123,7 +124,7 @@ def _ipc_worker(rank, world, port, q):
 def test_peer_group_processes_sharing_one_gpu(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + world
+    port = mp.get_context("spawn").Value("i", 0)      # rank 0 publishes the rendezvous port it bound
     procs = [ctx.Process(target=_ipc_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -158,7 +159,7 @@ def _ipc_strategy_worker(rank, world, port, q):
 
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        comm = Comm.init(rank, world, dev, master_port=port, timeout_s=60, backend="gloo")
+        comm = Comm.init(rank, world, dev, timeout_s=60, backend="gloo", port_cell=port)
         torch.manual_seed(0)
         st = CustomAllReduceStrategy(reference_mlp(dropout=0.0), comm, TrainConfig(loss_reduction="mean", seed=0),
                                      optimizer=Adam(1e-3), algorithm="ipc-direct")
@@ -188,7 +189,8 @@ def test_custom_strategy_on_peer_pointer_allreduce_matches_single_process():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ipc_strategy_worker, args=(r, world, 29671, q)) for r in range(world)]
+    cell = ctx.Value("i", 0)
+    procs = [ctx.Process(target=_ipc_strategy_worker, args=(r, world, cell, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -247,7 +249,7 @@ def _strategy_worker(rank, world, port, kinds, q):
 
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        comm = Comm.init(rank, world, dev, master_port=port, timeout_s=60, backend="gloo")
+        comm = Comm.init(rank, world, dev, timeout_s=60, backend="gloo", port_cell=port)
         g = torch.Generator().manual_seed(7)
         xs = torch.rand(6, 32 * world, 28, 28, 1, generator=g)
         ys = torch.randint(0, 10, (6, 32 * world), generator=g)
@@ -298,7 +300,8 @@ def two_rank_results():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_strategy_worker, args=(r, world, 29680, _KINDS, q)) for r in range(world)]
+    cell = ctx.Value("i", 0)
+    procs = [ctx.Process(target=_strategy_worker, args=(r, world, cell, _KINDS, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -344,3 +347,18 @@ def test_collective_strategies_two_ranks_on_one_gpu(kind, two_rank_results):
             ref.train_step(xs[i].to(dev), ys[i].to(dev))
         w_ref = np.concatenate([a.reshape(-1) for a in ref.replica.model.get_weights()])
         assert np.allclose(got[0]["w"], w_ref, atol=3e-5, rtol=1e-4), float(np.abs(got[0]["w"] - w_ref).max())
+
+
+def test_async_ps_loses_no_update_with_three_service_threads_per_owner_on_the_gpu():
+    """Four ranks share the GPU (gloo carries the tensors): every owner serves three workers from three host threads
+    that enqueue onto its one apply stream, next to the owner's own applies. Plain SGD with a power-of-two learning
+    rate on integer gradients is exact in fp32, so after 200 applies per shard the parameters must equal
+    init - lr * sum(gradients) bit for bit; a lost update, a doubled one or a torn reply would show."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_distributed_cpu import run_exact_async
+    world, steps = 4, 50
+    got = run_exact_async(world, "cuda:0", steps)
+    for r in range(world):
+        assert "error" not in got[r], got[r].get("error")
+        assert got[r]["applies"] == world * steps
+        assert got[r]["equal"], got[r]

@@ -13,16 +13,10 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.slow
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def _run(fn, world, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = ctx.Value("i", 0)      # rank 0 binds an ephemeral rendezvous port and publishes it here
     procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q, args)) for r in range(world)]
     for p in procs:
         p.start()
@@ -44,7 +38,7 @@ def _entry(fn, rank, world, port, q, args):
     sys.path.insert(0, ROOT)
     try:
         from distributed_tensorflow_amd.comm.backend import Comm
-        comm = Comm.init(rank, world, "cpu", "127.0.0.1", port, timeout_s=120)
+        comm = Comm.init(rank, world, "cpu", "127.0.0.1", 0, timeout_s=120, port_cell=port)
         res = fn(comm, *args)
         comm.barrier()
         q.put((rank, res))

@@ -943,3 +943,42 @@ def test_norm_relu_max_pool_in_one_pass_matches_the_separate_kernels(cfg):
     assert torch.allclose(a[1], b[1], atol=0.02 * float(b[1].abs().max()) + 1e-4, rtol=2e-2)
     for i in (2, 3, 4, 5):
         assert torch.allclose(a[i], b[i], atol=1e-3 * float(b[i].abs().max()) + 1e-5, rtol=1e-3), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("second", ["conv", "add"])
+def test_norm_output_with_two_consumers_falls_back_to_its_own_reduction(second):
+    """A batch-norm output that feeds a convolution AND something else (a second convolution, a plain add): the
+    gradient the norm receives is the sum over its consumers, so sums gathered by one convolution's data-gradient
+    GEMM must not be used. Gradients are checked against fp32 autograd of the same graph."""
+    from distributed_tensorflow_amd.ops import conv, norm
+    torch.manual_seed(31)
+    N, C, H = 4, 64, 12
+    x = torch.randn(N, C, H, H, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    g = (torch.rand(C, device=DEV) + 0.5)
+    b = torch.randn(C, device=DEV) * 0.2
+    w1 = (torch.randn(64, C, 3, 3, device=DEV) * 0.05).bfloat16().contiguous(memory_format=torch.channels_last)
+    w2 = (torch.randn(64, C, 1, 1, device=DEV) * 0.1).bfloat16().contiguous(memory_format=torch.channels_last)
+    wts = torch.rand(N, 64, H, H, device=DEV) + 0.5
+
+    def run(fp32):
+        xi = (x.float() if fp32 else x.clone()).requires_grad_(True)
+        gi, bi = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        a1 = (w1.float() if fp32 else w1.clone()).requires_grad_(True)
+        a2 = (w2.float() if fp32 else w2.clone()).requires_grad_(True)
+        if fp32:
+            y = torch.relu(torch.nn.functional.batch_norm(xi, None, None, gi, bi, True, 0.1, 1e-5))
+            o = torch.nn.functional.conv2d(y, a1, None, 1, 1)
+            o = o + (torch.nn.functional.conv2d(y, a2) if second == "conv" else y)
+        else:
+            y = norm.batch_norm_act(xi, gi, bi, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), True, 0.1, 1e-5,
+                                    True)
+            o = conv.conv2d(y, a1, 1, 1)
+            o = o + (conv.conv2d(y, a2) if second == "conv" else y)
+        (o.float() * wts).sum().backward()
+        return [t.grad.float() for t in (xi, gi, bi, a1, a2 if second == "conv" else a1)]
+
+    ref, got = run(True), run(False)
+    for r, a, name in zip(ref, got, ("dx", "dgamma", "dbeta", "dw1", "dw2")):
+        err = float((a - r).norm() / r.norm())
+        assert err < 3e-2, (name, err)

@@ -38,6 +38,14 @@ def test_str2bool_rejects_garbage():
         launcher.str2bool("maybe")
 
 
+def _probe_port():
+    """Separate commands have to be TOLD a port: probe a free one (single-command jobs use --port 0 instead)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _args(s):
     return launcher.build_parser().parse_args(s.split())
 
@@ -65,9 +73,9 @@ def _launch(flags, tmp_path, timeout=240):
 
 @pytest.mark.slow
 @pytest.mark.parametrize("flags,port", [
-    ("-m c -cs sync -n 2 -b 50 --transport tcp -ca y", 6201),
-    ("-m c -cs async -n 2 -b 50 --transport tcp", 6202),
-    ("-m c -cs sync -n 2 -b 50 --transport tcp --apply sequential", 6203),
+    ("-m c -cs sync -n 2 -b 50 --transport tcp -ca y", 0),
+    ("-m c -cs async -n 2 -b 50 --transport tcp", 0),
+    ("-m c -cs sync -n 2 -b 50 --transport tcp --apply sequential", 0),
 ])
 def test_centralized_tcp_end_to_end(flags, port, tmp_path):
     out, res = _launch(f"{flags} --port {port}", tmp_path)
@@ -103,7 +111,7 @@ def test_collective_strategies_end_to_end(flags, tmp_path):
 def test_worker_failure_ends_sync_job_with_error(tmp_path):
     """A worker killed mid-run must end the job with a non-zero exit, not hang it (the reference
     hangs in barrier.wait(), reference centralized/server.py:95)."""
-    cmd = [sys.executable, os.path.join(ROOT, "initializer.py"), *"-m c -cs sync -n 2 -b 50 --transport tcp --port 6210".split(),
+    cmd = [sys.executable, os.path.join(ROOT, "initializer.py"), *"-m c -cs sync -n 2 -b 50 --transport tcp --port 0".split(),
            "--device", "cpu", "--fault-inject", "1:3"]
     p = subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert p.returncode != 0
@@ -113,7 +121,7 @@ def test_worker_failure_ends_sync_job_with_error(tmp_path):
 def test_multi_machine_roles(tmp_path):
     """-tt server / -tt worker -ti k -sa ADDR (reference initializer.py:147-155), run as separate commands."""
     base = [sys.executable, os.path.join(ROOT, "initializer.py"), "-m", "c", "-cs", "sync", "-n", "2", "-b", "50",
-            "-sa", "127.0.0.1", "--port", "6220", "--device", "cpu"]
+            "-sa", "127.0.0.1", "--port", str(_probe_port()), "--device", "cpu"]
     srv = subprocess.Popen(base + ["-tt", "server"], env=ENV, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
     ws = [subprocess.Popen(base + ["-tt", "worker", "-ti", str(i)], env=ENV, stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True, cwd=ROOT) for i in range(2)]
