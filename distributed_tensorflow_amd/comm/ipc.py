@@ -303,12 +303,30 @@ class PeerGroup:
                                   self.status.data_ptr(), _lib.stream_ptr(self.device))
         _lib.check(rc, "p2p barrier")
 
-    def check(self) -> None:
-        """Host check of the barrier status word (synchronises the current stream)."""
-        s = int(self.status.item())
+    def _raise_if(self, s: int) -> None:
         if s:
             missing = [j for j in range(self.world) if s >> j & 1]
-            raise RuntimeError(f"peer-pointer barrier timed out waiting for ranks {missing}")
+            raise RuntimeError(f"peer-pointer barrier timed out waiting for ranks {missing}: the buffers reduced "
+                               "since then hold partial sums")
+
+    def check(self) -> None:
+        """Host check of the barrier status word (synchronises the current stream)."""
+        self._raise_if(int(self.status.item()))
+
+    def check_async(self) -> None:
+        """The once-per-step form of :meth:`check` without a host wait: raises if the snapshot of the status word
+        taken by the previous call shows a timed-out barrier, then enqueues a new snapshot (an asynchronous copy into
+        pinned host memory) behind the work submitted so far. A late or dead peer is therefore reported at most
+        one step after the barrier gave up on it."""
+        snap = getattr(self, "_snap", None)
+        if snap is None:
+            self._snap = snap = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        else:
+            host, ev = snap
+            ev.synchronize()        # recorded a whole step ago: returns at once
+            self._raise_if(int(host[0]))
+        snap[0].copy_(self.status, non_blocking=True)
+        snap[1].record()
 
     def all_reduce(self, t: torch.Tensor, algorithm: str = "auto", scale: float = 1.0, base: torch.Tensor | None = None):
         """All-reduce ``t``, a 16-byte aligned slice of the registered tensor ``base`` (default: ``t``

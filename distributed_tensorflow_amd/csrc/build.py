@@ -14,12 +14,16 @@ Two shared objects are produced under ``distributed_tensorflow_amd/lib``:
     ``librccl``.
 
 Objects are rebuilt only when their source (or a header) is newer, so calling
-:func:`build_all` repeatedly is cheap. Run ``python -m
+:func:`build_all` repeatedly is cheap. A build holds an exclusive file lock (several ranks that find the
+library missing build it once, one after the other finding it up to date) and links to a temporary name
+that is renamed into place, so no process ever maps a half-written library. Run ``python -m
 distributed_tensorflow_amd.csrc.build`` to build from the shell.
 """
 from __future__ import annotations
 
 import concurrent.futures as cf
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -71,7 +75,34 @@ def _compile_objects(srcs: list[Path], headers: list[Path], flags: list[str], ta
     return objs
 
 
+@contextlib.contextmanager
+def _build_lock():
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    with open(OBJ_DIR / ".lock", "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
+def _link(cmd_head: list[str], out: Path, tail: list[str]) -> None:
+    tmp = out.with_name(out.name + f".tmp{os.getpid()}")
+    _run([*cmd_head, "-o", str(tmp), *tail])
+    os.replace(tmp, out)
+
+
 def build_kernels(jobs: int = 8, force: bool = False) -> Path:
+    with _build_lock():
+        return _build_kernels(jobs, force)
+
+
+def build_runtime(jobs: int = 8, force: bool = False) -> Path:
+    with _build_lock():
+        return _build_runtime(jobs, force)
+
+
+def _build_kernels(jobs: int = 8, force: bool = False) -> Path:
     kdir = CSRC / "kernels"
     srcs = sorted(kdir.glob("*.hip"))
     headers = sorted(kdir.glob("*.h"))
@@ -83,7 +114,7 @@ def build_kernels(jobs: int = 8, force: bool = False) -> Path:
     objs = _compile_objects(srcs, headers, flags, "k", jobs)
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     if force or any(_newer(o, [], out) for o in objs) or _manifest_changed("k", objs):
-        _run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(out), *map(str, objs)])
+        _link([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}"], out, list(map(str, objs)))
     return out
 
 
@@ -98,7 +129,7 @@ def _manifest_changed(tag: str, objs: list[Path]) -> bool:
     return True
 
 
-def build_runtime(jobs: int = 8, force: bool = False) -> Path:
+def _build_runtime(jobs: int = 8, force: bool = False) -> Path:
     rdir = CSRC / "runtime"
     srcs = sorted(rdir.glob("*.cpp"))
     headers = sorted(rdir.glob("*.h"))
@@ -111,8 +142,8 @@ def build_runtime(jobs: int = 8, force: bool = False) -> Path:
     objs = _compile_objects(srcs, headers, flags + extra, "r", jobs)
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     if force or any(_newer(o, [], out) for o in objs):
-        _run([_hipcc(), "-shared", "-fPIC", "-pthread", "-o", str(out), *map(str, objs), *extra,
-              f"-L{ROCM / 'lib'}", "-lamdhip64", "-lrccl", f"-Wl,-rpath,{ROCM / 'lib'}"])
+        _link([_hipcc(), "-shared", "-fPIC", "-pthread"], out,
+              [*map(str, objs), *extra, f"-L{ROCM / 'lib'}", "-lamdhip64", "-lrccl", f"-Wl,-rpath,{ROCM / 'lib'}"])
     return out
 
 

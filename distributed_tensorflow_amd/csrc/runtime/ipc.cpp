@@ -76,15 +76,16 @@ DTF_API int dtf_ipc_close(const void* handle) {
   return (int)e;
 }
 
-// Fine-grained (coherent across agents) device memory for barrier flags; zero-filled.
+// Fine-grained (coherent across agents) device memory for barrier flags; zero-filled. There is no fallback to
+// ordinary (coarse-grained) memory: writes of another process to such memory are not guaranteed to become
+// visible while a kernel runs, so every cross-process barrier on it would time out.
 DTF_API int dtf_ipc_alloc_flags(unsigned long long bytes, void** out) {
   if (!out || bytes == 0) return -1;
   void* p = nullptr;
   hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return (int)e;
+    return (int)e;
   }
   e = hipMemset(p, 0, bytes);
   if (e != hipSuccess) { (void)hipFree(p); return (int)e; }

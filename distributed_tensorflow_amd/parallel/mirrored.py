@@ -115,7 +115,15 @@ class CustomAllReduceStrategy(Strategy):
                     torch.cuda.current_stream(self.comm.device).wait_event(ev)
         with phase("optimizer"):
             self.optimizer.step()
+        if self._peers is not None:
+            self._peers.check_async()     # a barrier that timed out means partial sums: stop, do not train on
         return loss
+
+    def finalize(self) -> None:
+        if self._peers is not None:
+            self._peers.check()
+            self._peers.close()
+            self._peers = None
 
 
 def circulant_neighbours(rank: int, world: int, degree: int) -> list[int]:
