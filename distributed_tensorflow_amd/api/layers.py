@@ -26,7 +26,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..ops import conv as _conv
 from ..ops import dense as _dense
+from ..ops import norm as _norm
 from ..ops import pool as _pool
 
 
@@ -151,12 +153,16 @@ class Dense(Layer):
 
 
 class Dropout(Layer):
+    """On a GPU the mask comes from the framework's device-resident Philox state (``ops/rng.py``) and is
+    regenerated, not stored, for the backward pass; ``Sequential`` fuses a ``Dropout`` that follows a ``Dense``
+    layer into that layer's GEMM epilogue, so this module only runs on its own behind other layers."""
+
     def __init__(self, rate: float):
         super().__init__()
         self.rate = rate
 
     def forward(self, x):
-        return F.dropout(x, self.rate, self.training)
+        return _dense.dropout(x, self.rate, self.training)
 
 
 class Activation(Layer):
@@ -223,14 +229,14 @@ class Conv2D(Layer):
         return (oh, ow, self.filters)
 
     def forward(self, x):
-        l, r, t, b = self._pads(x.shape[2], x.shape[3])
-        if l == r and t == b:
-            y = F.conv2d(x, self.weight, self.bias, self.strides, (t, l))
-        else:
-            y = F.conv2d(F.pad(x, (l, r, t, b)), self.weight, self.bias, self.strides)
+        pads = self._pads(x.shape[2], x.shape[3])
+        fused = "relu" if self.act_name == "relu" else None      # bias and ReLU ride the GEMM epilogue
+        y = _conv.conv2d_bias_act(x, self.weight, self.bias, self.strides, pads, fused)
+        if fused or self.act is None:
+            return y
         if self.act == "softmax":
             return torch.softmax(y.float(), dim=1).to(y.dtype)
-        return y if self.act is None else self.act(y)
+        return self.act(y)
 
     def keras_weights(self):
         ws = [np.ascontiguousarray(_to_np(self.weight).transpose(2, 3, 1, 0))]  # OIHW -> HWIO
@@ -261,7 +267,10 @@ class _Pool2D(Layer):
 
 class MaxPooling2D(_Pool2D):
     def forward(self, x):
-        return _pool.max_pool2d(x, self.pool_size, self.strides)
+        k, s = self.pool_size, self.strides
+        if k[0] == k[1] and s[0] == s[1]:
+            return _pool.max_pool2d(x, k[0], s[0])
+        return F.max_pool2d(x, k, s)
 
 
 class AveragePooling2D(_Pool2D):
@@ -292,7 +301,14 @@ class BatchNormalization(Layer):
         return in_shape
 
     def forward(self, x):
-        return self.bn(x)
+        bn = self.bn
+        if x.dim() == 4 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 \
+                and bn.weight.dtype == torch.float32:
+            if not x.is_contiguous(memory_format=torch.channels_last):
+                x = x.contiguous(memory_format=torch.channels_last)
+            return _norm.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
+                                        bn.momentum, bn.eps, relu=False)
+        return bn(x)
 
     def keras_weights(self):
         return [_to_np(self.bn.weight), _to_np(self.bn.bias), _to_np(self.bn.running_mean), _to_np(self.bn.running_var)]

@@ -29,6 +29,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from . import gemm as _gemm
+from . import gemm_any as _any
 
 _backend = os.environ.get("DTF_CONV1X1", "auto")
 _backend_kxk = os.environ.get("DTF_CONVKXK", "auto")
@@ -66,22 +67,28 @@ class _ConvFn(torch.autograd.Function):
     gradient is accumulated onto inside the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding, auto=False, stats=None, grad_req=None):
-        """``grad_req``: the ``ops.norm.GradStatsRequest`` of the batch norm that produced ``x``, if any.
+    def forward(ctx, x, w, stride, padding, auto=False, stats=None, grad_req=None, bias=None, activation=None,
+                out_hw=None):
+        """``bias`` / ``activation`` ('relu'): applied in the GEMM epilogue. ``out_hw``: output size when it is not
+        ``(H + 2 * padding - KH) // stride + 1`` -- ``padding`` counts at the top / left, the rest of an asymmetric
+        ('same') padding follows from the output size.
+        ``grad_req``: the ``ops.norm.GradStatsRequest`` of the batch norm that produced ``x``, if any.
         ``stats`` (optional, filled in place): fp32 ``[gemm.col_stats_rows(M, K), 2, K]`` partial batch-norm
         statistics of the output, accumulated in the GEMM's store phase."""
         N, C, H, W = x.shape
         K, _, KH, KW = w.shape
-        OH = (H + 2 * padding - KH) // stride + 1
-        OW = (W + 2 * padding - KW) // stride + 1
+        OH, OW = out_hw if out_hw is not None else ((H + 2 * padding - KH) // stride + 1,
+                                                    (W + 2 * padding - KW) // stride + 1)
         y = torch.empty((N, OH, OW, K), dtype=x.dtype, device=x.device)
         M = N * OH * OW
         if KH == 1 and KW == 1 and stride == 1 and padding == 0:
-            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, C, C, C, K, col_stats=stats)
+            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, C, C, C, K, col_stats=stats, bias=bias, activation=activation)
         else:
             ex = _gemm.conv_geom(_gemm.CONV_FWD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
-            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, KH * KW * C, C, KH * KW * C, K, extra=ex, col_stats=stats)
-        ctx.save_for_backward(x, w)
+            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, KH * KW * C, C, KH * KW * C, K, extra=ex, col_stats=stats,
+                           bias=bias, activation=activation)
+        ctx.save_for_backward(x, w, y if activation == "relu" else None)
+        ctx.bias_dtype = bias.dtype if bias is not None else None
         ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, stride, padding)
         ctx.auto = auto
         ctx.grad_req = grad_req
@@ -91,10 +98,15 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, gy, g_alias=None):
         """``g_alias`` (fork variant only): gradient that arrived through the aliased input; it is
         added to the data gradient inside the GEMM epilogue instead of by a separate add kernel."""
-        x, w = ctx.saved_tensors
+        x, w, y_act = ctx.saved_tensors
         N, C, H, W, K, KH, KW, OH, OW, stride, padding = ctx.geom
         if not gy.is_contiguous(memory_format=torch.channels_last):
             gy = gy.contiguous(memory_format=torch.channels_last)
+        gb = None
+        if y_act is not None:          # ReLU from the epilogue: mask the incoming gradient by the saved output
+            gy = _gemm.relu_bwd(gy.permute(0, 2, 3, 1), y_act).permute(0, 3, 1, 2)
+        if ctx.bias_dtype is not None and ctx.needs_input_grad[7]:
+            gb = _gemm.col_sum(gy.permute(0, 2, 3, 1).reshape(-1, K), dtype=ctx.bias_dtype)
         # a norm-add-ReLU that took the alias as its residual may have handed over its incoming gradient
         # unmasked, with the mask to apply (ops.norm.ForkToken)
         alias_mask = None
@@ -167,7 +179,7 @@ class _ConvFn(torch.autograd.Function):
                 ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex)
             gw = gw.permute(0, 3, 1, 2)        # [K, C, KH, KW] with channels_last strides
-        return gx, gw, None, None, None, None, None
+        return gx, gw, None, None, None, None, None, gb, None, None
 
 
 def up2_geom(KH, KW, stride, padding, H, W) -> bool:
@@ -193,7 +205,7 @@ class _ConvForkFn(_ConvFn):
             if tk is not None and tk.masked_grad is not None:
                 g_alias, tk.masked_grad = _apply_mask_bits(g_alias, tk.masked_grad[2]), None
             return g_alias, None, None, None, None, None, None, None
-        return _ConvFn.backward(ctx, gy, g_alias) + (None,)
+        return _ConvFn.backward(ctx, gy, g_alias)[:7] + (None,)
 
 
 def pad_channels(x: torch.Tensor, cp: int) -> torch.Tensor:
@@ -233,11 +245,11 @@ class _FirstConvFn(torch.autograd.Function):
         return wp
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding, stats=None):
+    def forward(ctx, x, w, stride, padding, stats=None, bias=None, activation=None, out_hw=None):
         N, C, H, W = x.shape
         K, _, KH, KW = w.shape
-        OH = (H + 2 * padding - KH) // stride + 1
-        OW = (W + 2 * padding - KW) // stride + 1
+        OH, OW = out_hw if out_hw is not None else ((H + 2 * padding - KH) // stride + 1,
+                                                    (W + 2 * padding - KW) // stride + 1)
         g = _FirstConvFn._geometry(C, H, W, KH, KW, stride, padding)
         xp = pad_channels(x, g["cp"])
         wp = _FirstConvFn._pad_weight(w, g)
@@ -256,8 +268,10 @@ class _FirstConvFn(torch.autograd.Function):
                 r = _gemm.col_stats_rows(M, K)
                 st = stats[rows:rows + r]
                 rows += r
-            _gemm.gemm_raw(_gemm.NT, xp[b0:b1], wp, y[b0:b1], M, K, kdim, g["civ"], kdim, K, extra=ex, col_stats=st)
-        ctx.save_for_backward(xp, w)
+            _gemm.gemm_raw(_gemm.NT, xp[b0:b1], wp, y[b0:b1], M, K, kdim, g["civ"], kdim, K, extra=ex, col_stats=st,
+                           bias=bias, activation=activation)
+        ctx.save_for_backward(xp, w, y if activation == "relu" else None)
+        ctx.bias_dtype = bias.dtype if bias is not None else None
         ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, stride, padding, nb)
         return y.permute(0, 3, 1, 2)
 
@@ -275,13 +289,17 @@ class _FirstConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        xp, w = ctx.saved_tensors
+        xp, w, y_act = ctx.saved_tensors
         N, C, H, W, K, KH, KW, OH, OW, stride, padding, nb = ctx.geom
         g = _FirstConvFn._geometry(C, H, W, KH, KW, stride, padding)
         if not gy.is_contiguous(memory_format=torch.channels_last):
             gy = gy.contiguous(memory_format=torch.channels_last)
         gyn = gy.permute(0, 2, 3, 1)
-        gx = gw = None
+        if y_act is not None:
+            gyn = _gemm.relu_bwd(gyn, y_act)
+        gx = gw = gb = None
+        if ctx.bias_dtype is not None and ctx.needs_input_grad[5]:
+            gb = _gemm.col_sum(gyn.reshape(-1, K), dtype=ctx.bias_dtype)
         if ctx.needs_input_grad[1]:
             ncol = g["kwv"] * g["civ"]
             fold = ncol <= 64
@@ -320,7 +338,7 @@ class _FirstConvFn(torch.autograd.Function):
                 _gemm.gemm_raw(_gemm.NN, gyn[b0:b1], w8, gx8[b0:b1], (b1 - b0) * H * W, cp8, KH * KW * K, K,
                                KH * KW * cp8, cp8, extra=ex)
             gx = gx8[..., :C].permute(0, 3, 1, 2)
-        return gx, gw, None, None, None
+        return gx, gw, None, None, None, gb, None, None
 
 
 def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -426,3 +444,82 @@ def conv2d_fork(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int 
         y, st = conv2d(x, w, stride, padding, True)
         return y, x, st
     return conv2d(x, w, stride, padding), x
+
+
+class _ConvAnyFn(torch.autograd.Function):
+    """Convolution as patch matrix x weight matrix on the general-purpose exact-fp32 MFMA GEMM: the GPU path of
+    fp32 layers and of geometries the implicit-GEMM kernel does not take (rectangular strides, odd channel counts
+    deeper in a network). im2col and its transpose are the framework's own gather kernels; the patch matrix is
+    rebuilt in the backward pass rather than kept."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, sh, sw, pt, pl, OH, OW, activation):
+        N, C, H, W = x.shape
+        K, _, KH, KW = w.shape
+        xn = x.permute(0, 2, 3, 1).contiguous()
+        wm = w.permute(0, 2, 3, 1).reshape(K, KH * KW * C)
+        plain = KH == 1 and KW == 1 and sh == 1 and sw == 1 and pt == 0 and pl == 0
+        cols = xn.reshape(-1, C) if plain else _any.im2col(xn, KH, KW, sh, sw, pt, pl, OH, OW)
+        y = _any.matmul(cols, wm.t(), bias=bias, activation="relu" if activation == "relu" else None,
+                        out_dtype=x.dtype)
+        ctx.save_for_backward(xn, w, y if activation == "relu" else None)
+        ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, sh, sw, pt, pl, plain)
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        return y.view(N, OH, OW, K).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xn, w, y_act = ctx.saved_tensors
+        N, C, H, W, K, KH, KW, OH, OW, sh, sw, pt, pl, plain = ctx.geom
+        g = gy.permute(0, 2, 3, 1).reshape(-1, K)
+        if not g.is_contiguous():
+            g = g.contiguous()
+        if y_act is not None:
+            g = _any.ew_f32(0, g, y_act) if g.dtype == torch.float32 else _gemm.relu_bwd(g, y_act)
+        gx = gw = gb = None
+        wm = w.permute(0, 2, 3, 1).reshape(K, KH * KW * C)
+        if ctx.needs_input_grad[0]:
+            gcols = _any.matmul(g, wm, out_dtype=xn.dtype)
+            gxn = gcols.view(N, H, W, C) if plain else _any.col2im(gcols, (N, H, W, C), KH, KW, sh, sw, pt, pl, OH, OW)
+            gx = gxn.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            cols = xn.reshape(-1, C) if plain else _any.im2col(xn, KH, KW, sh, sw, pt, pl, OH, OW)
+            gw = _any.matmul(g.t(), cols, out_dtype=w.dtype).view(K, KH, KW, C).permute(0, 3, 1, 2)
+        if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
+            gb = g.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
+        return gx, gw, gb, None, None, None, None, None, None, None
+
+
+def conv2d_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, strides=(1, 1),
+                    pads=(0, 0, 0, 0), activation: str | None = None) -> torch.Tensor:
+    """Keras-style convolution layer ``act(conv(x, w) + bias)`` on a channels_last activation. ``pads`` = (left,
+    right, top, bottom), as TensorFlow's 'same' computes them (the odd pixel at the end); ``activation``: None or
+    'relu' (fused), anything else is left to the caller. On a GPU every case runs on the framework's own kernels:
+    bf16 with square strides on the implicit-GEMM kernel (bias and ReLU in its epilogue), the rest as patch matrix
+    times weight matrix on the general-purpose MFMA GEMM."""
+    sh, sw = strides
+    pl, pr, pt, pb = pads
+    N, C, H, W = x.shape
+    K, _, KH, KW = w.shape
+    OH = (H + pt + pb - KH) // sh + 1
+    OW = (W + pl + pr - KW) // sw + 1
+    act = "relu" if activation == "relu" else None
+    if x.is_cuda and w.is_cuda:
+        if x.dtype != w.dtype:
+            x = x.to(w.dtype)
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
+        square = sh == sw and pt == pl and _backend_kxk != "library"
+        if square and x.dtype == torch.bfloat16 and N * max(H * W, OH * OW) < (1 << 24):
+            if _own_path(x, wc, sh, "gemm"):
+                return _ConvFn.apply(x, wc, sh, pt, False, None, None, bias, act, (OH, OW))
+            if _first_layer_path(x, wc, sh, "gemm"):
+                return _FirstConvFn.apply(x, wc, sh, pt, None, bias, act, (OH, OW))
+        if x.dtype in (torch.float32, torch.bfloat16):
+            return _ConvAnyFn.apply(x, wc, bias, sh, sw, pt, pl, OH, OW, act)
+    if pl == pr and pt == pb:
+        y = F.conv2d(x, w, bias, (sh, sw), (pt, pl))
+    else:
+        y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, bias, (sh, sw))
+    return F.relu(y) if act == "relu" else y

@@ -3,8 +3,9 @@
 On a GPU with bf16 operands the forward, the data gradient and the weight
 gradient run on the hand-written MFMA GEMM (``ops/gemm.py``) with bias and
 ReLU/GELU applied in the epilogue, and the bias gradient is a fused column
-reduction; fp32 operands use the exact f32 library GEMM. On CPU the same maths
-runs in plain torch. This is the MatMul + BiasAdd + ReLU chain of the
+reduction; fp32 operands, and bf16 ones whose rows are not 16-byte aligned, run
+on the general-purpose exact-fp32 MFMA GEMM (``ops/gemm_any.py``), also with
+bias and activation in its epilogue. On CPU the same maths runs in plain torch. This is the MatMul + BiasAdd + ReLU chain of the
 reference model (reference initializer.py:16-18).
 """
 from __future__ import annotations
@@ -13,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import gemm as _gemm
+from . import gemm_any as _any
 from . import rng as _rng
 
 
@@ -82,6 +84,67 @@ class _LinearFn(torch.autograd.Function):
             gx = gx.reshape(ctx.x_shape)
             if g_alias is not None:
                 gx = gx + g_alias
+        return gx, gw, gb, None, None
+
+
+class _LinearAnyFn(torch.autograd.Function):
+    """GPU path of everything the bf16 tile kernel does not take (fp32 layers, unaligned rows): the three products
+    on the general-purpose MFMA GEMM, which reads the operands through their strides (no transposed copies)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, activation, drop_p=0.0):
+        x2 = x.reshape(-1, x.shape[-1])
+        odt = torch.float32 if torch.float32 in (x.dtype, w.dtype) else torch.bfloat16
+        # ReLU rides the GEMM epilogue; GELU keeps its pre-activation for the backward pass
+        y = _any.matmul(x2, w.t(), bias=b, activation="relu" if activation == "relu" else None, out_dtype=odt)
+        pre = None
+        if activation == "gelu":
+            pre = y
+            y = _any.ew_f32(2, pre) if odt == torch.float32 else _gemm.gelu_fwd(pre)
+        ctx.drop = None
+        if drop_p > 0.0:
+            st = _rng.state_for(x.device)
+            ctx.drop = (drop_p, st.seed, st.snapshot())
+            y = _any.ew_f32(3, y, p=drop_p, seed=st.seed, off=ctx.drop[2]) if y.dtype == torch.float32 \
+                else _gemm.dropout_fwd(y, *ctx.drop)
+            st.advance(y.numel())
+        ctx.activation = activation
+        ctx.bias_dtype = b.dtype if b is not None else None
+        ctx.x_shape = x.shape
+        ctx.save_for_backward(x2, w, pre if activation == "gelu" else (y if activation == "relu" else None))
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, saved = ctx.saved_tensors
+        g = gy.reshape(-1, gy.shape[-1])
+        if g.dtype == torch.float32:
+            if ctx.drop is not None:
+                p, seed, off = ctx.drop
+                if ctx.activation == "relu":      # y > 0 already implies "kept": only the 1 / (1 - p) scale is needed
+                    g = _any.ew_f32(0, g, saved, scale=1.0 / (1.0 - p))
+                elif ctx.activation == "gelu":
+                    g = _any.ew_f32(1, g, saved, p=p, seed=seed, off=off)
+                else:
+                    g = _any.ew_f32(3, g, p=p, seed=seed, off=off)
+            elif ctx.activation == "relu":
+                g = _any.ew_f32(0, g, saved)
+            elif ctx.activation == "gelu":
+                g = _any.ew_f32(1, g, saved)
+        else:
+            if ctx.drop is not None:
+                g = _gemm.dropout_bwd(g, *ctx.drop, activation=ctx.activation, saved=saved)
+            elif ctx.activation == "relu":
+                g = _gemm.relu_bwd(g, saved)
+            elif ctx.activation == "gelu":
+                g = _gemm.gelu_bwd(g, saved)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _any.matmul(g, w, out_dtype=x2.dtype).reshape(ctx.x_shape)            # [M, K] = g [M, N] @ w [N, K]
+        if ctx.needs_input_grad[1]:
+            gw = _any.matmul(g.t(), x2, out_dtype=w.dtype)                             # [N, K] = g^T [N, M] @ x [M, K]
+        if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
+            gb = g.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
         return gx, gw, gb, None, None
 
 
@@ -170,6 +233,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = No
     p = float(dropout_p) if training else 0.0
     if x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and _gemm.supported(x, weight):
         return _LinearFn.apply(x, weight, bias, activation, p)
+    if x.is_cuda and weight.is_cuda and x.numel() > 0 and x.dtype in (torch.float32, torch.bfloat16) \
+            and weight.dtype in (torch.float32, torch.bfloat16):
+        return _LinearAnyFn.apply(x, weight, bias, activation, p)
     if x.dtype != weight.dtype:
         x = x.to(weight.dtype)
     y = F.linear(x, weight, bias.to(weight.dtype) if bias is not None else None)
@@ -184,3 +250,37 @@ def linear_fork(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
             and x.requires_grad and torch.is_grad_enabled()):
         return _LinearForkFn.apply(x, weight, bias, activation, 0.0)
     return linear(x, weight, bias, activation), x
+
+
+class _DropoutFn(torch.autograd.Function):
+    """Stand-alone dropout on the GPU: Philox mask from ``(seed, device-resident offset)``, regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        st = _rng.state_for(x.device)
+        ctx.drop = (p, st.seed, st.snapshot())
+        y = _any.ew_f32(3, x, p=p, seed=st.seed, off=ctx.drop[2]) if x.dtype == torch.float32 \
+            else _gemm.dropout_fwd(x, *ctx.drop)
+        st.advance(x.numel())
+        return y.view(x.shape) if y.shape != x.shape else y
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed, off = ctx.drop
+        out = _any.ew_f32(3, g, p=p, seed=seed, off=off) if g.dtype == torch.float32 \
+            else _gemm.dropout_bwd(g, p, seed, off)
+        return out.view(g.shape), None
+
+
+def dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    """Inverted dropout. GPU fp32 / bf16 tensors draw their mask from the framework's Philox state in memory order
+    (a channels_last activation keeps its layout); CPU tensors use torch's generator."""
+    if not training or p <= 0.0:
+        return x
+    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0:
+        if x.is_contiguous():
+            return _DropoutFn.apply(x, float(p))
+        if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+            return _DropoutFn.apply(x.permute(0, 2, 3, 1), float(p)).permute(0, 3, 1, 2)
+        return _DropoutFn.apply(x.contiguous(), float(p))
+    return F.dropout(x, p, True)

@@ -982,3 +982,138 @@ def test_norm_output_with_two_consumers_falls_back_to_its_own_reduction(second):
     for r, a, name in zip(ref, got, ("dx", "dgamma", "dbeta", "dw1", "dw2")):
         err = float((a - r).norm() / r.norm())
         assert err < 3e-2, (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(100, 512, 784), (100, 10, 512), (7, 3, 5), (64, 64, 16), (257, 130, 1000), (33, 1000, 2048)])
+@pytest.mark.parametrize("dts", [("f", "f"), ("b", "b"), ("f", "b")])
+def test_general_gemm_matches_fp32_reference_in_every_layout(M, N, K, dts):
+    """NT / NN / TN products through strided views (nothing is copied), fp32 and bf16 operands, unaligned sizes."""
+    from distributed_tensorflow_amd.ops import gemm_any as G
+    torch.manual_seed(M + N + K)
+    dt = {"f": torch.float32, "b": torch.bfloat16}
+    a = torch.randn(M, K, device=DEV).to(dt[dts[0]])
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(dt[dts[1]])
+    bias = torch.randn(N, device=DEV)
+    ref = a.float() @ w.float().t()
+    tol = dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(G.matmul(a, w.t(), out_dtype=torch.float32), ref, **tol)                  # NT
+    torch.testing.assert_close(G.matmul(a, w.t(), bias=bias, activation="relu", out_dtype=torch.float32),
+                               torch.relu(ref + bias), **tol)
+    g = torch.randn(M, N, device=DEV).to(dt[dts[0]])
+    torch.testing.assert_close(G.matmul(g, w, out_dtype=torch.float32), g.float() @ w.float(), **tol)    # NN
+    torch.testing.assert_close(G.matmul(g.t(), a, out_dtype=torch.float32), g.float().t() @ a.float(), **tol)   # TN
+    if K >= 1000:   # the split-K path (slabs + ordered reduction) must agree with the single pass
+        torch.testing.assert_close(G.matmul(a, w.t(), out_dtype=torch.float32, splits=5), ref, **tol)
+    out_b = G.matmul(a, w.t(), bias=bias, out_dtype=torch.bfloat16)
+    torch.testing.assert_close(out_b.float(), (ref + bias).bfloat16().float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reference_mlp_layers_run_on_own_kernels_and_match_torch(dtype):
+    """The reference model's two dense layers (784 -> 512 relu, dropout, 512 -> 10) in fp32 -- the launcher's default
+    -- and in bf16 (where the 10-column layer is not 16-byte aligned): forward and gradients against fp32 torch."""
+    from distributed_tensorflow_amd.ops import dense
+    torch.manual_seed(3)
+    x = torch.rand(100, 784, device=DEV).to(dtype)
+    w1 = (torch.randn(512, 784, device=DEV) * 0.05).to(dtype).requires_grad_(True)
+    b1 = torch.zeros(512, device=DEV, requires_grad=True)
+    w2 = (torch.randn(10, 512, device=DEV) * 0.05).to(dtype).requires_grad_(True)
+    b2 = torch.zeros(10, device=DEV, requires_grad=True)
+    h = dense.linear(x, w1, b1, activation="relu")
+    y = dense.linear(h, w2, b2)
+    gy = torch.randn(100, 10, device=DEV)
+    y.backward(gy.to(y.dtype))
+    got = [y.float(), w1.grad.float(), b1.grad.float(), w2.grad.float(), b2.grad.float()]
+    w1r, b1r = w1.detach().float().requires_grad_(True), b1.detach().clone().requires_grad_(True)
+    w2r, b2r = w2.detach().float().requires_grad_(True), b2.detach().clone().requires_grad_(True)
+    hr = torch.relu(x.float() @ w1r.t() + b1r)
+    yr = hr @ w2r.t() + b2r
+    yr.backward(gy.to(y.dtype).float())
+    ref = [yr.detach(), w1r.grad, b1r.grad, w2r.grad, b2r.grad]
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    for a, r in zip(got, ref):
+        scale = max(1.0, float(r.abs().max()))
+        torch.testing.assert_close(a / scale, r / scale, **tol)
+
+
+@pytest.mark.gpu
+def test_fp32_dropout_in_dense_layer_regenerates_its_mask_in_backward():
+    from distributed_tensorflow_amd.ops import dense, rng
+    torch.manual_seed(9)
+    x = torch.randn(64, 96, device=DEV)
+    w = (torch.randn(48, 96, device=DEV) * 0.1).requires_grad_(True)
+    st = rng.state_for(torch.device(DEV))
+    off0 = int(st.offset.item())
+    y = dense.linear(x, w, None, activation="relu", dropout_p=0.25, training=True)
+    keep = torch.from_numpy(rng.dropout_keep_mask_reference(st.seed, off0, y.numel(), 0.25)).to(DEV).reshape(y.shape)
+    ref = torch.relu(x @ w.detach().t()) * keep / 0.75
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+    y.backward(torch.ones_like(y))
+    gref = ((keep / 0.75) * (ref > 0)).t() @ x
+    torch.testing.assert_close(w.grad, gref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_keras_style_cnn_layers_match_torch_reference(dtype):
+    """Conv2D ('valid' and 'same', stride 1 and 2, bias + ReLU) -> MaxPooling2D -> Flatten -> Dense layers of the
+    Keras-style API, forward and every parameter gradient against the same network written with fp32 torch ops."""
+    import torch.nn.functional as F
+    from distributed_tensorflow_amd.api.layers import Conv2D, Dense, Flatten, MaxPooling2D
+    from distributed_tensorflow_amd.api.model import Sequential
+    torch.manual_seed(17)
+    net = Sequential([Conv2D(32, 3, padding="same", activation="relu", input_shape=(28, 28, 1)), MaxPooling2D(2),
+                      Conv2D(64, 3, strides=2, padding="same", activation="relu"), Conv2D(16, 3, padding="same"),
+                      Flatten(), Dense(40, activation="relu"), Dense(10, activation="softmax")]).to(DEV)
+    for p in net.parameters():
+        if p.dim() > 1:
+            p.data = p.data.to(dtype)
+            if p.dim() == 4:
+                p.data = p.data.contiguous(memory_format=torch.channels_last)
+    for p in net.parameters():
+        if p.dim() == 1:
+            p.data.normal_(0, 0.1)
+    x = torch.rand(12, 28, 28, 1, device=DEV)
+    out = net(x, logits=True)
+    assert out.shape == (12, 10)
+    gy = torch.randn(12, 10, device=DEV)
+    out.float().backward(gy)
+    got = [out.float()] + [p.grad.float() for p in net.parameters()]
+
+    ps = [p.detach().float().requires_grad_(True) for p in net.parameters()]
+    w1, b1, w2, b2, w3, b3, w4, b4, w5, b5 = ps
+    h = x.to(dtype).float().permute(0, 3, 1, 2)
+    h = F.max_pool2d(F.relu(F.conv2d(h, w1, b1, padding=1)), 2)           # 28 -> 14
+    h = F.relu(F.conv2d(F.pad(h, (0, 1, 0, 1)), w2, b2, stride=2))         # 'same', stride 2 on 14: pad 0 / 1 -> 7
+    h = F.conv2d(h, w3, b3, padding=1)
+    h = h.permute(0, 2, 3, 1).reshape(12, -1)                              # Keras flattens in NHWC order
+    h = F.relu(h @ w4.t() + b4)
+    ref_out = h @ w5.t() + b5
+    ref_out.backward(gy)
+    ref = [ref_out.detach()] + [p.grad for p in ps]
+    # bf16: five layers of bf16-rounded activations against an fp32 evaluation (each layer has its own tight test)
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=1e-1, atol=1e-1)
+    for a, r in zip(got, ref):
+        scale = max(1.0, float(r.abs().max()))
+        torch.testing.assert_close(a / scale, r / scale, **tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_standalone_dropout_layer_uses_the_philox_state(dtype):
+    from distributed_tensorflow_amd.ops import dense, rng
+    torch.manual_seed(4)
+    x = torch.randn(6, 16, 5, 7, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    st = rng.state_for(torch.device(DEV))
+    off0 = int(st.offset.item())
+    y = dense.dropout(x, 0.3, True)
+    assert y.shape == x.shape and y.is_contiguous(memory_format=torch.channels_last)
+    keep = torch.from_numpy(rng.dropout_keep_mask_reference(st.seed, off0, x.numel(), 0.3)).to(DEV)
+    keep = keep.reshape(6, 5, 7, 16).permute(0, 3, 1, 2)                   # the mask follows memory (NHWC) order
+    ref = (x.detach().float() * keep / 0.7).to(dtype)
+    torch.testing.assert_close(y.float(), ref.float(), rtol=1e-2, atol=1e-3)
+    y.float().sum().backward()
+    torch.testing.assert_close(x.grad.float(), (keep / 0.7).float().to(dtype).float(), rtol=1e-2, atol=1e-3)
+    assert int(st.offset.item()) == off0 + (x.numel() + 3) // 4
