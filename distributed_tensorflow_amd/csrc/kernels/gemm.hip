@@ -113,6 +113,14 @@ struct GemmArgs {
   // [NB][H][W] image and zeros at its three neighbours (2a, 2b+1), (2a+1, 2b), (2a+1, 2b+1): the data gradient of a
   // 1x1 convolution of stride 2 as one GEMM over the pixels that were read. H, W in cv.
   int up2;
+  // Operand transform (template flag TF: 1 = A operand, 2 = B operand): the operand is the INPUT of a batch norm whose
+  // normalised (and rectified) output this product consumes; every element becomes bf16(relu(fma(x, tf_scale[c],
+  // tf_shift[c]))) between its load and the LDS store, c = its channel. Elements outside the operand (tile edges,
+  // convolution padding) stay zero: the padding of a convolution pads the ACTIVATION. The norm's apply pass over
+  // that tensor (one read, one write) does not run.
+  const float* tf_scale;
+  const float* tf_shift;
+  int tf_relu;
   ConvGeom cv;
 };
 
@@ -194,11 +202,13 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rs, bool ok, 
 // ROWS = 128 or 64 rows per tile. A 64-row tile has half the chunks (two per thread); its row-contiguous image keeps
 // the 256-byte k-rows of the 128-row one (only chunks 0..7 are filled), so both read with the same swizzle.
 
-template <int T, int GATHER, int ROWS>   // GATHER: 0 plain, 1 conv forward x, 2 conv dgrad dy, 3 conv wgrad x, 4 conv dgrad w
+template <int T, int GATHER, int ROWS, bool TF = false>   // GATHER: 0 plain, 1 conv forward x, 2 conv dgrad dy, 3 conv wgrad x, 4 conv dgrad w
 struct Stager {
   static constexpr int NCH = ROWS / 32;    // 16-byte chunks per thread
   static constexpr int RCB = ROWS == 64 ? 3 : 4;   // T = 1: log2(row chunks per k-row)
   u32x4 r[NCH];
+  unsigned okmask;   // TF: bit i = chunk i of the tile in r[] holds operand data (not an edge / padding zero)
+  int tfc;           // TF: channel of the first element of this thread's chunks in that tile
   int base[NCH];       // element offset of the row's first tap (GATHER 1, 2; see init)
   int ca[NCH], cb[NCH];  // ih0 / iw0 (GATHER 1) or ih+P / iw+P (GATHER 2)
   bool rowok[NCH];
@@ -251,22 +261,26 @@ struct Stager {
     if (T == 0) {
       const int k = k0 + ((threadIdx.x & 7) << 3);
       const bool kok = k < kend;
+      if (TF) { okmask = 0u; tfc = kok ? k : 0; }
       if (GATHER == 0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
           const int row = row0 + ((threadIdx.x + kThreads * i) >> 3);
           r[i] = buf_load16(rs, row < rows && kok, (unsigned)row * uld + (unsigned)k);
+          if (TF) okmask |= (row < rows && kok ? 1u : 0u) << i;
         }
       } else if (GATHER == 1) {             // k = (kh, kw, ci)
         int t, ci, kh, kw;
         divmod(kok ? k : 0, c.CI, c.r_ci, t, ci);
         divmod(t, c.KW, c.r_kw, kh, kw);
         const int tapo = (kh * c.W + kw) * c.CI + ci;
+        if (TF) tfc = ci;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
           const int ih = ca[i] + kh, iw = cb[i] + kw;
           const bool ok = rowok[i] && kok && (unsigned)ih < (unsigned)c.H && (unsigned)iw < (unsigned)c.W;
           r[i] = buf_load16(rs, ok, (unsigned)(base[i] + tapo));
+          if (TF) okmask |= (ok ? 1u : 0u) << i;
         }
       } else {                              // GATHER 2: k = (kh, kw, co), source pixel ((ih+P-kh)/S, (iw+P-kw)/S)
         int t, co, kh, kw;
@@ -297,6 +311,7 @@ struct Stager {
       const int kf = k0 + kg * NCH;         // this thread's first k of the tile; k = kf + i
       // one divmod per tile; the following k are reached by increment-with-carry
       int t = 0, co = 0, n = 0, oh = 0, ow = 0;
+      if (TF) { okmask = 0u; tfc = GATHER == 3 ? coff : (rok ? row : 0); }
       if (GATHER == 4) divmod(kf < kend ? kf : 0, c.CO, c.r_co, t, co);
       if (GATHER == 3) {
         int rem;
@@ -309,16 +324,39 @@ struct Stager {
         const bool ok = rok && k < kend;
         if (GATHER == 0) {
           r[i] = buf_load16(rs, ok, (unsigned)k * uld + (unsigned)row);
+          if (TF) okmask |= (ok ? 1u : 0u) << i;
         } else if (GATHER == 4) {           // weights for dgrad: k = (tap, co) -> w[co][tap][ci = row]
           r[i] = buf_load16(rs, ok, (unsigned)co * uld + (unsigned)(t * c.CI + row));
         } else {                            // GATHER 3: k = output pixel, tap fixed: x[(n, oh*S+kh-P, ow*S+kw-P)][row]
           const int ih = oh * c.S + tkh - c.P, iw = ow * c.SW + tkw - c.PW;
-          r[i] = buf_load16(rs, ok && (unsigned)ih < (unsigned)c.H && (unsigned)iw < (unsigned)c.W,
-                            (unsigned)(((n * c.H + ih) * c.W + iw) * c.CI + coff));
+          const bool in = ok && (unsigned)ih < (unsigned)c.H && (unsigned)iw < (unsigned)c.W;
+          r[i] = buf_load16(rs, in, (unsigned)(((n * c.H + ih) * c.W + iw) * c.CI + coff));
+          if (TF) okmask |= (in ? 1u : 0u) << i;
         }
         if (GATHER == 4) { if (++co == c.CO) { co = 0; ++t; } }
         if (GATHER == 3) { if (++ow == c.OW) { ow = 0; if (++oh == c.OH) { oh = 0; ++n; } } }
       }
+    }
+  }
+
+  // bf16(relu(fma(x, scale[c], shift[c]))) on the chunks of the tile in r[]; chunks without operand data stay zero
+  __device__ __forceinline__ void transform(const GemmArgs& g) {
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(g.tf_scale + tfc), s1 = *reinterpret_cast<const f32x4*>(g.tf_scale + tfc + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(g.tf_shift + tfc), h1 = *reinterpret_cast<const f32x4*>(g.tf_shift + tfc + 4);
+    const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      u32x4 v = r[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lo = fmaf(__uint_as_float(v[e] << 16), sc[2 * e], sh[2 * e]);
+        float hi = fmaf(__uint_as_float(v[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]);
+        if (g.tf_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+        v[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+      }
+      const bool ok = (okmask >> i) & 1u;
+      r[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
     }
   }
 
@@ -366,7 +404,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 // V selects the output tile: 0 = 128 x 128 (waves 2 x 2, 64 x 64 each), 1 = 128 x 64 (waves 4 x 1, 32 x 64 each) for
 // products at most 64 columns wide (the 64-channel layers of a ResNet, a convolution stem): half the accumulators,
 // half the B tile, four resident blocks per CU instead of three.
-template <int A_T, int B_T, int CONV, int STAGES, int V>
+template <int A_T, int B_T, int CONV, int STAGES, int V, int TF = 0>
 __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES x (A tile, B tile)
   constexpr int BN_ = V ? 64 : 128;          // tile columns
@@ -415,8 +453,8 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
 
   constexpr int GA = CONV == 1 ? 1 : CONV == 2 ? 2 : CONV == 4 ? 3 : 0;
   constexpr int GB = CONV == 2 ? 4 : CONV == 3 ? 3 : 0;
-  Stager<A_T, GA, BM> sa;
-  Stager<B_T, GB, BN_> sb;
+  Stager<A_T, GA, BM, TF == 1> sa;
+  Stager<B_T, GB, BN_, TF == 2> sb;
   sa.init(g, g.M, m0, tap);
   sb.init(g, g.N, n0, tap);
 
@@ -499,6 +537,8 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
       sb.load(g, Bp, g.ldb, g.N, n0, kbeg + t * BK, kend, tap);
     }
     while (t < nt) {
+      if (TF == 1) sa.transform(g);
+      if (TF == 2) sb.transform(g);
       sa.store(smem);
       sb.store(smem + kTileBytes);
       __syncthreads();
@@ -816,6 +856,9 @@ struct GemmExtra {
   int fold;                          // weight gradient: planes are kernel rows, N = KW * CI (see ConvGeom)
   int tile;                          // 0 = 128 x 128 output tile, 1 = 128 x 64
   int up2;                           // plain NN product stored at every other pixel of an [NB][H][W] image (see GemmArgs)
+  const void* tf_scale;              // operand transform (see GemmArgs): fp32 per-channel scale / shift of the batch norm
+  const void* tf_shift;              //   whose output this product consumes, applied to the image operand while staging
+  int tf_relu;
 };
 
 // Sums fp32 split-K slabs [splits][M][N] into C (bias, activation, conversion); shared with gemm256.hip.
@@ -848,6 +891,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   g.col_stats = nullptr; g.stats_mode = 0; g.bn_relu = 0;
   g.bn_x = nullptr; g.bn_mean = g.bn_scale = g.bn_shift = nullptr; g.bn_mask = nullptr;
   g.up2 = 0;
+  g.tf_scale = g.tf_shift = nullptr; g.tf_relu = 0;
   const int variant = ex && ex->tile == 1 ? 1 : 0;
   const int bn_cols = variant ? 64 : BN;
   g.tiles_n = (N + bn_cols - 1) / bn_cols;
@@ -887,6 +931,14 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
       }
     }
     conv = ex->conv;
+    if (ex->tf_scale) {
+      if (!ex->tf_shift || (batch > 1 && conv != 3) || !((layout == 0 && (conv == 0 || conv == 1)) ||
+                                           (layout == 2 && (conv == 0 || conv == 3 || conv == 4))))
+        return -13;
+      // the channel of an operand element is its k index (1x1) or its column (weight gradients): whole 8-channel chunks
+      if ((layout == 0 && conv == 0 && K % 8) || (layout == 2 && conv == 0 && N % 8)) return -13;
+      g.tf_scale = (const float*)ex->tf_scale; g.tf_shift = (const float*)ex->tf_shift; g.tf_relu = ex->tf_relu;
+    }
     if (ex->up2) {
       // rows are the pixels a stride-2 1x1 convolution read: bf16 output written by this kernel's own epilogue
       if (conv || layout != 1 || out_fp32 || batch > 1 || ex->col_stats || ex->Cin || ((ex->H | ex->W) & 1) ||
@@ -935,7 +987,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   // (k-tiles per block <= kSingleStageTiles) are latency- and bandwidth-bound and run better with one
   // buffer and twice the resident blocks. g_stages overrides (1 or 2) for A/B measurements.
   const int k_tiles = kps / BK;
-  const int stages = g_stages == 1 || g_stages == 2 ? g_stages : (k_tiles <= kSingleStageTiles ? 1 : 2);
+  const int stages = g.tf_scale ? 1 : g_stages == 1 || g_stages == 2 ? g_stages : (k_tiles <= kSingleStageTiles ? 1 : 2);
   // LDS per stage: A image + B image (a row-contiguous B keeps 256-byte k-rows in either variant)
   const size_t b_tile = (layout == 0 && variant ? 64 : 128) * BK * 2;
   const size_t stage_bytes = kTileBytes + b_tile;
@@ -946,7 +998,18 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
     else if (stages == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 2, 0>), grid, dim3(kThreads), lds, stream, g); \
     else hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 1, 0>), grid, dim3(kThreads), lds, stream, g);     \
   } while (0)
-  if (conv == 0) {
+#define GEMM_LAUNCH_TF(AT, BT, CV, TFS)                                                                         \
+  do {                                                                                                         \
+    if (variant) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 1, 1, TFS>), grid, dim3(kThreads), lds, stream, g); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 1, 0, TFS>), grid, dim3(kThreads), lds, stream, g);  \
+  } while (0)
+  if (g.tf_scale) {
+    if (layout == 0 && conv == 0) GEMM_LAUNCH_TF(0, 0, 0, 1);
+    else if (layout == 0 && conv == 1) GEMM_LAUNCH_TF(0, 0, 1, 1);
+    else if (layout == 2 && conv == 0) GEMM_LAUNCH_TF(1, 1, 0, 2);
+    else if (layout == 2 && conv == 3) GEMM_LAUNCH_TF(1, 1, 3, 2);
+    else GEMM_LAUNCH_TF(1, 1, 4, 1);
+  } else if (conv == 0) {
     switch (layout) {
       case 0: GEMM_LAUNCH(0, 0, 0); break;
       case 1: GEMM_LAUNCH(0, 1, 0); break;
@@ -959,6 +1022,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   else if (conv == 4 && layout == 2) GEMM_LAUNCH(1, 1, 4);
   else return -1;
 #undef GEMM_LAUNCH
+#undef GEMM_LAUNCH_TF
   if (splits > 1) {
     const long long n4 = (long long)M * (N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n4, 16), batch), dim3(kBlock), 0, stream,

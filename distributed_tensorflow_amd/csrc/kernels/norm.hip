@@ -339,9 +339,12 @@ DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, cons
   }
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, part, np, gamma,
                      beta, run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
-  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
-                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
-                     (unsigned char*)mask_out, M, C, relu);
+  // y == null: the consumer of the normalised activation applies scale / shift (/ ReLU) itself while it stages its
+  // operand (gemm.hip, operand transform); only the statistics are finished here
+  if (y)
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+                       (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
+                       (unsigned char*)mask_out, M, C, relu);
   return (int)hipGetLastError();
 }
 

@@ -71,6 +71,16 @@ class BNAct(nn.Module):
                                        self.training, self.momentum, self.eps, self.relu, residual,
                                        partials if self.training else None)
 
+    def deferred(self, x, partials):
+        """The norm with its apply pass left to the convolution that consumes it (``ops.norm.DeferredNorm``) when
+        that is possible (training, statistics handed over by the producer, bf16 GPU fast path), else the tensor."""
+        if self.training and partials is not None:
+            d = norm_ops.batch_norm_deferred(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                             self.momentum, self.eps, self.relu, partials)
+            if d is not None:
+                return d
+        return self.forward(x, partials=partials)
+
     def keras_weights(self):
         return [t.detach().float().cpu().numpy() for t in (self.weight, self.bias, self.running_mean, self.running_var)]
 
@@ -112,8 +122,14 @@ class Bottleneck(nn.Module):
         else:
             (y, xi), st = conv_ops.conv2d_fork(x, c1.weight, c1.stride, c1.padding), None
         idt = xi if self.down is None else _conv_bn(self.down, self.down_bn, xi)
-        y = self.bn1(y, partials=st)
-        y = _conv_bn(self.conv2, self.bn2, y)
+        # bn1 and bn2 have one consumer each, the next convolution: it normalises while it stages its operand, so
+        # their normalised outputs are never written
+        y = self.bn1.deferred(y, st)
+        if self.training:
+            y, st = self.conv2(y, bn_stats=True)
+            y = self.bn2.deferred(y, st)
+        else:
+            y = self.bn2(self.conv2(y))
         return _conv_bn(self.conv3, self.bn3, y, residual=idt)   # relu(bn(conv) + identity) in one fused pass
 
 

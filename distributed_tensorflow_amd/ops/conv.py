@@ -68,8 +68,10 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, stride, padding, auto=False, stats=None, grad_req=None, bias=None, activation=None,
-                out_hw=None):
-        """``bias`` / ``activation`` ('relu'): applied in the GEMM epilogue. ``out_hw``: output size when it is not
+                out_hw=None, in_scale=None, in_shift=None, in_relu=False):
+        """``in_scale`` / ``in_shift`` / ``in_relu``: ``x`` is the INPUT of a batch norm whose apply pass was deferred
+        (``ops.norm.DeferredNorm``); the product normalises (and rectifies) it while staging, here and in the weight
+        gradient. ``bias`` / ``activation`` ('relu'): applied in the GEMM epilogue. ``out_hw``: output size when it is not
         ``(H + 2 * padding - KH) // stride + 1`` -- ``padding`` counts at the top / left, the rest of an asymmetric
         ('same') padding follows from the output size.
         ``grad_req``: the ``ops.norm.GradStatsRequest`` of the batch norm that produced ``x``, if any.
@@ -81,12 +83,14 @@ class _ConvFn(torch.autograd.Function):
                                                     (W + 2 * padding - KW) // stride + 1)
         y = torch.empty((N, OH, OW, K), dtype=x.dtype, device=x.device)
         M = N * OH * OW
+        ctx.in_bn = in_bn = (in_scale, in_shift, in_relu) if in_scale is not None else None
         if KH == 1 and KW == 1 and stride == 1 and padding == 0:
-            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, C, C, C, K, col_stats=stats, bias=bias, activation=activation)
+            _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, C, C, C, K, col_stats=stats, bias=bias, activation=activation,
+                           in_bn=in_bn)
         else:
             ex = _gemm.conv_geom(_gemm.CONV_FWD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
             _gemm.gemm_raw(_gemm.NT, x, w, y, M, K, KH * KW * C, C, KH * KW * C, K, extra=ex, col_stats=stats,
-                           bias=bias, activation=activation)
+                           bias=bias, activation=activation, in_bn=in_bn)
         ctx.save_for_backward(x, w, y if activation == "relu" else None)
         ctx.bias_dtype = bias.dtype if bias is not None else None
         ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, stride, padding)
@@ -166,20 +170,21 @@ class _ConvFn(torch.autograd.Function):
             gx = g_alias if gx is None else gx + g_alias
         if want_w:
             gw = torch.empty((K, KH, KW, C), dtype=w.dtype, device=x.device)
+            in_bn = ctx.in_bn         # the activation operand is a deferred norm's input: normalised while staged
             if plain:
-                _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, C)
+                _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, C, in_bn=in_bn)
             elif K <= 64 and _wgrad_t:
                 # narrow layer: the transposed product, every tap side by side in the rows (dy is re-read once per
                 # 128 of them instead of once per tap)
                 ex = _gemm.conv_geom(_gemm.CONV_WGRAD_T, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
                 gwt = torch.empty((KH * KW * C, K), dtype=w.dtype, device=x.device)
-                _gemm.gemm_raw(_gemm.TN, x, gy, gwt, KH * KW * C, K, N * OH * OW, C, K, K, extra=ex)
+                _gemm.gemm_raw(_gemm.TN, x, gy, gwt, KH * KW * C, K, N * OH * OW, C, K, K, extra=ex, in_bn=in_bn)
                 gw = gwt.t().contiguous().view(K, KH, KW, C)
             else:
                 ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
-                _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex)
+                _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex, in_bn=in_bn)
             gw = gw.permute(0, 3, 1, 2)        # [K, C, KH, KW] with channels_last strides
-        return gx, gw, None, None, None, None, None, gb, None, None
+        return gx, gw, None, None, None, None, None, gb, None, None, None, None, None
 
 
 def up2_geom(KH, KW, stride, padding, H, W) -> bool:
@@ -402,13 +407,23 @@ def _stats_buffer(x, w, stride, padding):
 
 
 def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0, bn_stats: bool = False):
-    """Bias-free convolution of a channels_last activation with an ``[O, I, kh, kw]`` weight.
+    """Bias-free convolution of a channels_last activation (or of an ``ops.norm.DeferredNorm``: the norm is then
+    applied while the operand is staged) with an ``[O, I, kh, kw]`` weight.
     ``bn_stats=True`` returns ``(y, partials)``: ``partials`` are the per-channel sums and sums of squares of
     ``y`` over disjoint row sets, accumulated while the GEMM stores ``y`` (pass them to
     ``ops.norm.batch_norm_act(..., partials=)``, which then reads ``y`` once instead of twice), or ``None`` when
     the convolution did not run on the framework's own kernel."""
     one = w.shape[2] == 1 and w.shape[3] == 1
     backend = _backend if one else _backend_kxk
+    from . import norm as _norm
+    if isinstance(x, _norm.DeferredNorm):
+        dn, x = x, x.tensor
+        if _own_path(x, w, stride, backend):
+            st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
+            y = _ConvFn.apply(x, w, stride, padding, backend == "auto", st, _norm_request(x), None, None, None,
+                              dn.scale, dn.shift, dn.relu)
+            return (y, st) if bn_stats else y
+        x = dn.materialize()
     if _own_path(x, w, stride, backend):
         st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
         y = _ConvFn.apply(x, w, stride, padding, backend == "auto", st, _norm_request(x))

@@ -56,7 +56,8 @@ class GemmExtra(ctypes.Structure):
                 ("bn_mean", ctypes.c_void_p), ("bn_scale", ctypes.c_void_p), ("bn_shift", ctypes.c_void_p),
                 ("bn_mask", ctypes.c_void_p), ("cin_mask", ctypes.c_void_p),
                 ("SW", ctypes.c_int), ("PW", ctypes.c_int), ("use_sw", ctypes.c_int), ("fold", ctypes.c_int),
-                ("tile", ctypes.c_int), ("up2", ctypes.c_int)]
+                ("tile", ctypes.c_int), ("up2", ctypes.c_int),
+                ("tf_scale", ctypes.c_void_p), ("tf_shift", ctypes.c_void_p), ("tf_relu", ctypes.c_int)]
 
 
 CONV_FWD, CONV_DGRAD, CONV_WGRAD, CONV_WGRAD_T = 1, 2, 3, 4
@@ -306,12 +307,23 @@ def col_stats_rows(M: int, N: int) -> int:
 def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int,
              ldb: int, ldc: int, extra: GemmExtra | None = None, bias=None, activation=None, splits=None,
              add: torch.Tensor | None = None, col_stats: torch.Tensor | None = None, bn_grad=None,
-             add_mask: torch.Tensor | None = None):
+             add_mask: torch.Tensor | None = None, in_bn=None):
     """Unchecked launch on explicit dimensions and leading dimensions (batched attention products,
     implicit-GEMM convolutions). ``add`` is a bf16 tensor laid out like ``out`` that is added to the
     result in the epilogue. ``col_stats`` (fp32 ``[col_stats_rows(M, N), 2, N]``)
     receives per-wave-row column sums and sums of squares of the bf16 output, the partial statistics of a
-    batch norm that follows. The caller guarantees 16-byte alignment of every row it addresses."""
+    batch norm that follows. ``in_bn = (scale, shift, relu)`` (fp32 per-channel vectors): the image operand (A of a
+    forward product, the activation operand of a weight gradient) is the INPUT of a batch norm and is normalised
+    (and rectified) while it is staged, see ``ops.norm.batch_norm_deferred``.
+    The caller guarantees 16-byte alignment of every row it addresses."""
+    if in_bn is not None:
+        sc, sh, relu = in_bn
+        if sc.dtype != torch.float32 or sh.dtype != torch.float32 or not (sc.is_contiguous() and sh.is_contiguous()):
+            raise ValueError("gemm_raw: in_bn scale / shift must be contiguous fp32 vectors")
+        if extra is None:
+            extra = GemmExtra()
+            extra.nb1 = extra.nb2 = 1
+        extra.tf_scale, extra.tf_shift, extra.tf_relu = sc.data_ptr(), sh.data_ptr(), int(bool(relu))
     if col_stats is not None:
         if (col_stats.dtype != torch.float32 or not col_stats.is_contiguous() or out.dtype != torch.bfloat16
                 or tuple(col_stats.shape) != (col_stats_rows(M, N), 2, N)):

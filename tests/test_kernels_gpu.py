@@ -1117,3 +1117,50 @@ def test_standalone_dropout_layer_uses_the_philox_state(dtype):
     y.float().sum().backward()
     torch.testing.assert_close(x.grad.float(), (keep / 0.7).float().to(dtype).float(), rtol=1e-2, atol=1e-3)
     assert int(st.offset.item()) == off0 + (x.numel() + 3) // 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    # (N, C, H, W, K, k, stride, pad)
+    (3, 128, 14, 14, 128, 3, 1, 1), (2, 128, 28, 28, 128, 3, 2, 1), (4, 64, 14, 14, 256, 1, 1, 0),
+    (3, 64, 18, 18, 64, 3, 1, 1), (2, 64, 20, 20, 64, 3, 2, 1), (5, 256, 7, 7, 64, 1, 1, 0), (2, 72, 9, 11, 200, 3, 1, 1),
+])
+def test_deferred_norm_is_applied_by_the_consuming_convolution(cfg):
+    """conv(DeferredNorm) == conv(relu(bn(x))): the operand transform computes the very bf16 values the norm's apply
+    kernel would have written, so the output and the weight gradient agree bit for bit; the data gradient and the
+    norm's own gradients agree up to the order of the norm's backward sums."""
+    from distributed_tensorflow_amd.ops import conv, norm
+    N, C, H, W, K, k, stride, pad = cfg
+    torch.manual_seed(sum(cfg))
+    x0 = (torch.randn(N, C, H, W, device=DEV) * 1.5 + 0.3).bfloat16().contiguous(memory_format=torch.channels_last)
+    wp = (torch.randn(C, C, 1, 1, device=DEV) * 0.1).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(K, C, k, k, device=DEV) / math.sqrt(C * k * k)).bfloat16().contiguous(memory_format=torch.channels_last)
+    gamma0, beta0 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+    res = {}
+    norm.set_deferred(True)
+    for mode in ("deferred", "materialized", "classic"):
+        x = x0.clone().requires_grad_(True)
+        w1 = w.clone().requires_grad_(True)
+        g, b = gamma0.clone().requires_grad_(True), beta0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        z, st = conv.conv2d(x, wp, 1, 0, bn_stats=True)            # producer: hands its statistics over
+        if mode == "classic":
+            a = norm.batch_norm_act(z, g, b, rm, rv, True, 0.1, 1e-5, True, None, st)
+        else:
+            a = norm.batch_norm_deferred(z, g, b, rm, rv, 0.1, 1e-5, True, st)
+            assert isinstance(a, norm.DeferredNorm)
+            if mode == "materialized":
+                a = a.materialize()
+        y = conv.conv2d(a, w1, stride, pad)
+        gy = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2)).bfloat16()
+        y.backward(gy)
+        res[mode] = [y.detach().float(), x.grad.float(), w1.grad.float(), g.grad.float(), b.grad.float(), rm, rv]
+    norm.set_deferred(False)
+    for name, a, m_, c in zip(("y", "dx", "dw", "dgamma", "dbeta", "run_mean", "run_var"), *res.values()):
+        if name in ("y", "dw", "run_mean", "run_var"):     # same bf16 operand values, same accumulation order
+            assert torch.equal(a, m_), (name, "deferred vs materialized", float((a - m_).abs().max()))
+        # the norm's backward sums come from the convolution's epilogue in one path and from the norm's own
+        # reduction in the others: same value up to the summation order
+        for other in (m_, c):
+            scale = max(1.0, float(other.abs().max()))
+            torch.testing.assert_close(a / scale, other / scale, rtol=1e-2, atol=1e-2, msg=lambda m: name + ": " + m)
