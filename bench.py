@@ -49,7 +49,7 @@ def main() -> int:
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"], help="cpu is for plumbing tests only")
     ap.add_argument("--model", default="resnet50", choices=["resnet50", "bert", "bert-tiny"])
     ap.add_argument("--strategy", default=None,
-                    help="keras | custom[:direct|ring|multiring|tree|oneshot] | ipc[-direct|-oneshot|-ring|-tree] | "
+                    help="keras | custom[:direct|ring|multiring|tree|oneshot] | ipc[-direct|-fused|-oneshot|-ring|-tree] | "
                          "graph[:degree] | sync | async (default: keras for resnet50, custom:ring for bert)")
     ap.add_argument("--grad-dtype", default="bf16", choices=["bf16", "fp32"], help="dtype the gradients are exchanged in")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph")

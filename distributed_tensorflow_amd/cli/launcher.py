@@ -77,7 +77,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--placement", choices=["colocated", "dedicated"], default="colocated",
                    help="async collective PS: shard owners are the workers | one extra server rank")
     p.add_argument("--algorithm", default="auto", help="custom strategy: auto|direct|ring|multiring|tree|oneshot on grouped send/recv, or "
-                   "ipc|ipc-direct|ipc-oneshot|ipc-ring|ipc-tree: kernels on HIP IPC mapped peer arenas")
+                   "ipc|ipc-direct|ipc-fused|ipc-oneshot|ipc-ring|ipc-tree: kernels on HIP IPC mapped peer arenas (ipc-fused: one launch per bucket)")
     p.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
     p.add_argument("--port", type=int, default=6000,
                    help="parameter-server port (reference: 6000); 0 = one the operating system picks (single machine)")

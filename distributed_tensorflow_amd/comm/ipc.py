@@ -13,6 +13,9 @@ Schedules (``plan``):
 ``oneshot``  every rank sums the whole buffer of all peers into scratch (one hop; small buffers)
 ``ring``     the classic 2(W-1)-step ring, kept for comparison: it is bound by ONE link
 ``tree``     binomial reduce to rank 0 + binomial broadcast: log2(W) hops for tiny buffers
+``fused``    the ``direct`` schedule as ONE kernel launch per rank: a small resident grid runs entry barrier,
+             reduce-scatter, barrier, all-gather and exit barrier itself (grid counters inside the device, growing
+             sequence numbers in the peers' flag arrays), instead of five launches per bucket
 
 The schedule is pure Python data, so it is verified on the CPU by an emulator
 (:func:`emulate`) that also detects read/write races inside a phase; the kernels are verified
@@ -165,6 +168,11 @@ def _k():
         lib.dtf_p2p_reduce.argtypes = [ctypes.POINTER(vp), i, vp, ll, ll, i, ctypes.c_float, i, vp]
         lib.dtf_p2p_gather.argtypes = [ctypes.POINTER(vp), i, i, vp, ll, ll, i, vp]
         lib.dtf_p2p_barrier.argtypes = [ctypes.POINTER(vp), i, i, ctypes.c_uint, i, vp, vp]
+        lib.dtf_p2p_allreduce_fused.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), i, i, vp, vp, ll, ll, i,
+                                                ctypes.c_float, ctypes.c_uint, ctypes.c_uint, i, i, vp]
+        lib.dtf_p2p_allreduce_fused_virtual.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), i, ctypes.POINTER(vp),
+                                                        ctypes.POINTER(vp), ll, ll, i, ctypes.c_float, ctypes.c_uint,
+                                                        ctypes.c_uint, i, i, vp]
         lib._p2p_declared = True
     return lib
 
@@ -229,12 +237,44 @@ class LocalPeers:
         self.world = len(bufs)
         self.scratch = [torch.empty_like(b) for b in bufs]
 
+    def _fused(self, scale: float, start: int, n: int, blocks: int = 8, budget_ms: int = 5000) -> None:
+        """The single-launch all-reduce with the W virtual ranks as the rows of ONE grid, so that they are resident
+        together by construction; each row runs the code of a real rank against its own counters, flag array and
+        status word and synchronises with the others exactly as W processes would."""
+        b0 = self.bufs[0]
+        dev = b0.device
+        if not hasattr(self, "_fz"):
+            rt = _rt()
+            flags = []
+            for _ in range(self.world):
+                p = ctypes.c_void_p()
+                _lib.check(rt.dtf_ipc_alloc_flags(4 * 64, ctypes.byref(p)), "flag allocation")
+                flags.append(p.value)
+            self._fz = dict(flags=flags, local=[torch.zeros(2, dtype=torch.int32, device=dev) for _ in self.bufs],
+                            status=[torch.zeros(1, dtype=torch.int32, device=dev) for _ in self.bufs],
+                            seq=0, arrive=0, blocks=blocks)
+        z = self._fz
+        if blocks != z["blocks"]:
+            raise ValueError("the fused all-reduce keeps one grid size per group")
+        rc = _k().dtf_p2p_allreduce_fused_virtual(
+            _ptr_array([b.data_ptr() for b in self.bufs]), _ptr_array(z["flags"]), self.world,
+            _ptr_array([t.data_ptr() for t in z["local"]]), _ptr_array([t.data_ptr() for t in z["status"]]), start, n,
+            _lib.dtype_code(b0.dtype), scale, z["seq"], z["arrive"], blocks, budget_ms, _lib.stream_ptr(dev))
+        _lib.check(rc, "p2p allreduce_fused (virtual ranks)")
+        z["seq"] += 3
+        z["arrive"] += 3 * blocks
+
+    def fused_status(self) -> list[int]:
+        return [int(t.item()) for t in self._fz["status"]]
+
     def all_reduce(self, algorithm: str = "direct", scale: float = 1.0, start: int = 0, numel: int | None = None):
         b0 = self.bufs[0]
         n = b0.numel() - start if numel is None else numel
         esz = b0.element_size()
         if (start * esz) % ALIGN_BYTES:
             raise ValueError("region must start on a 16-byte boundary")
+        if algorithm == "fused":
+            return self._fused(scale, start, n)
         ptrs = [b.data_ptr() for b in self.bufs]
         plans = [plan(algorithm, r, self.world, n, esz, scale) for r in range(self.world)]
         ex = [_Executor(r, self.world, b0.device) for r in range(self.world)]
@@ -261,6 +301,9 @@ class PeerGroup:
         _lib.check(rt.dtf_ipc_alloc_flags(4 * 64, ctypes.byref(p)), "flag allocation")
         self._flags_own = p.value
         self._flag_ptrs = self._map(self._flags_own)
+        # the single-launch all-reduce counts in words of its own (16 words into each rank's flag array)
+        self._fused_flag_ptrs = [q + 64 for q in self._flag_ptrs]
+        self.fused_blocks = max_blocks if 0 < max_blocks <= 64 else 32     # resident at once, leaves CUs to backward
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._registered: dict[int, tuple[list[int], torch.Tensor]] = {}
 
@@ -340,6 +383,18 @@ class PeerGroup:
             raise ValueError("the reduced slice must be contiguous and start on a 16-byte boundary")
         if algorithm == "auto":
             algorithm = pick_algorithm(t.numel() * esz, self.world)
+        if algorithm == "fused":
+            if not hasattr(self, "_fused_local"):
+                self._fused_local = torch.zeros(2, dtype=torch.int32, device=self.device)
+                self._fused_seq = self._fused_arrive = 0
+            rc = _k().dtf_p2p_allreduce_fused(_ptr_array(ptrs), _ptr_array(self._fused_flag_ptrs), self.world, self.rank,
+                                              self._fused_local.data_ptr(), self.status.data_ptr(), start, t.numel(),
+                                              _lib.dtype_code(t.dtype), scale, self._fused_seq, self._fused_arrive,
+                                              self.fused_blocks, self._budget, _lib.stream_ptr(self.device))
+            _lib.check(rc, "p2p allreduce_fused")
+            self._fused_seq += 3
+            self._fused_arrive += 3 * self.fused_blocks
+            return algorithm
         phases = plan(algorithm, self.rank, self.world, t.numel(), esz, scale)
         if self.world > 1:
             self.barrier()

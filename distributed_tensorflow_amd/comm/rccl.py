@@ -37,6 +37,7 @@ def _rt():
         lib.dtf_rccl_unique_id.argtypes = [vp, i]
         lib.dtf_rccl_init.argtypes = [vp, i, i, i, ctypes.POINTER(i)]
         lib.dtf_rccl_init.restype = vp
+        lib.dtf_rccl_split.argtypes = [vp, i, i, ctypes.POINTER(vp)]
         lib.dtf_rccl_all_reduce.argtypes = [vp, vp, vp, ull, i, i, vp]
         lib.dtf_rccl_reduce_scatter.argtypes = [vp, vp, vp, ull, i, i, vp]
         lib.dtf_rccl_all_gather.argtypes = [vp, vp, vp, ull, i, vp]
@@ -133,8 +134,31 @@ class RcclComm(Comm):
             _check(rc.value or -1, "ncclCommInitRank")
         return cls(rank, world, device, h, uid)
 
-    def subgroup(self, ranks):  # pragma: no cover - needs several GPUs
-        raise NotImplementedError("sub-communicators of the native binding are created with RcclComm.create")
+    def subgroup(self, ranks) -> "RcclComm":
+        """A communicator over ``ranks`` by ``ncclCommSplit`` (collective on this communicator: every rank calls it,
+        members and non-members alike, in the same order). A non-member gets a placeholder with rank -1, as
+        :meth:`Comm.subgroup` does; the asynchronous parameter server builds its per-pair communicators this way."""
+        ranks = list(ranks)
+        member = self.rank in ranks
+        out = ctypes.c_void_p(0)
+        _check(_rt().dtf_rccl_split(self._h, 0 if member else -1, ranks.index(self.rank) if member else 0,
+                                    ctypes.byref(out)), "ncclCommSplit")
+        if not member:
+            c = RcclComm(-1, len(ranks), self.device, 0)
+        else:
+            c = RcclComm(ranks.index(self.rank), len(ranks), self.device, out.value)
+        c._global_ranks = ranks
+        c.backend = "nccl"
+        return c
+
+    def async_error(self):
+        """Error string of an asynchronous RCCL failure, or None (polled by ``comm.watchdog.Watchdog``)."""
+        if not self._h:
+            return None
+        err = ctypes.c_int(0)
+        if _rt().dtf_rccl_async_error(self._h, ctypes.byref(err)) != 0:
+            return "ncclCommGetAsyncError failed"
+        return _rt().dtf_rccl_error_string(err.value).decode() if err.value != 0 else None
 
     def shutdown(self) -> None:
         if self._h:

@@ -194,3 +194,265 @@ DTF_API int dtf_p2p_barrier(unsigned* const* flags, int world, int rank, unsigne
   hipLaunchKernelGGL(p2p_barrier_kernel, dim3(1), dim3(kWave), 0, stream, fp, rank, world, epoch, ticks, status);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The one-hop all-reduce (reduce-scatter + all-gather) as ONE launch per rank instead of five (barrier, reduce,
+// barrier, gather, barrier): a small resident grid (capped so that the backward pass keeps its CUs) walks through
+//   entry barrier -> rank r sums shard r of every peer into its own buffer -> barrier -> pull the other ranks'
+//   finished shards -> exit barrier (nobody may overwrite a shard a peer is still reading).
+// A barrier has two levels. Inside the grid: every block drains its stores, a lane makes them visible beyond the
+// device (system-scope release: peers read this memory over xGMI) and adds to an arrival counter; block 0 waits for
+// all of them. Across ranks: lane j of block 0 writes this rank's growing sequence number into peer j's flag array
+// (fine-grained memory) and polls its own array for peer j's; then it releases the local blocks through a second
+// counter, and every block acquires at system scope before it touches peer memory again. Every wait is bounded by a
+// wall-clock budget: on expiry a bit is set in *status and the kernel carries on, so the grid always drains and the
+// host learns that the result is not to be trusted (comm/ipc.py checks the status word every step).
+// Counters and flags only grow; the host passes the sequence base of each call.
+namespace {
+
+struct FusedArgs {
+  PeerPtrs bufs;          // element 0 of every rank's registered buffer
+  FlagPtrs flags;         // every rank's flag array (world words each)
+  unsigned* local;        // this rank's two grid counters: [0] arrivals, [1] releases (device memory)
+  unsigned* status;
+  long long off, n, shard;   // region [off, off + n) in elements, shard = elements per rank (16-byte multiple)
+  long long budget;
+  float scale;
+  int rank, world;
+  unsigned seq;           // barrier sequence number before this call (3 barriers per call)
+  unsigned arrive_base;   // arrivals counted before this call (grid size x 3 per earlier call)
+};
+
+__device__ __forceinline__ void fused_barrier(const FusedArgs& a, unsigned k) {
+  // k = 1, 2, 3: the call's k-th barrier
+  __syncthreads();
+  const unsigned grid = gridDim.x;
+  if (threadIdx.x == 0) {
+    __threadfence_system();                                   // this block's stores, visible to the peers
+    __hip_atomic_fetch_add(a.local, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      const unsigned want = a.arrive_base + grid * k;
+      const long long t0 = wall_clock64();
+      while ((int)(__hip_atomic_load(a.local, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        if (wall_clock64() - t0 > a.budget) { atomicOr(a.status, 1u << 30); break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (j < a.world) {
+      const unsigned val = a.seq + k;
+      __hip_atomic_store(a.flags.p[j] + a.rank, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      const long long t0 = wall_clock64();
+      while ((int)(__hip_atomic_load(a.flags.p[a.rank] + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - val) < 0) {
+        if (wall_clock64() - t0 > a.budget) { atomicOr(a.status, 1u << j); break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(a.local + 1, a.seq + k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (threadIdx.x == 0) {
+    const unsigned val = a.seq + k;
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(a.local + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - val) < 0) {
+      if (wall_clock64() - t0 > 2 * a.budget) { atomicOr(a.status, 1u << 29); break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");              // system scope: no stale copy of peer memory
+}
+
+template <int W, typename T>
+__device__ __forceinline__ void fused_body(const FusedArgs& a) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int PER = 16 / (int)sizeof(T);                    // elements per 16-byte access
+  const long long stride = (long long)gridDim.x * kBlock;
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  fused_barrier(a, 1);
+  // ---- reduce-scatter: this rank's shard, summed over the ranks in rank order (same bits on every rank)
+  {
+    const long long lo = min((long long)a.rank * a.shard, a.n);
+    const long long cnt = max(0ll, min(a.shard, a.n - lo));
+    const long long nv = cnt / PER;
+    T* out = reinterpret_cast<T*>(const_cast<void*>(a.bufs.p[a.rank])) + a.off + lo;
+    for (long long i = tid; i < nv; i += stride) {
+      u32x4 v[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.bufs.p[j]) + a.off + lo) + i);
+      u32x4 o;
+      if (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float s = __uint_as_float(v[0][e]);
+#pragma unroll
+          for (int j = 1; j < W; ++j) s += __uint_as_float(v[j][e]);
+          o[e] = __float_as_uint(s * a.scale);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float s0 = __uint_as_float(v[0][e] << 16), s1 = __uint_as_float(v[0][e] & 0xffff0000u);
+#pragma unroll
+          for (int j = 1; j < W; ++j) {
+            s0 += __uint_as_float(v[j][e] << 16);
+            s1 += __uint_as_float(v[j][e] & 0xffff0000u);
+          }
+          o[e] = (unsigned)f32_to_bf16(s0 * a.scale) | ((unsigned)f32_to_bf16(s1 * a.scale) << 16);
+        }
+      }
+      reinterpret_cast<u32x4*>(out)[i] = o;
+    }
+    for (long long i = nv * PER + tid; i < cnt; i += stride) {   // tail of the last shard
+      float s = 0.f;
+      for (int j = 0; j < W; ++j) {
+        const T* p = reinterpret_cast<const T*>(a.bufs.p[j]) + a.off + lo + i;
+        s += sizeof(T) == 4 ? *reinterpret_cast<const float*>(p) : bf16_to_f32(*reinterpret_cast<const unsigned short*>(p));
+      }
+      s *= a.scale;
+      if (sizeof(T) == 4) *reinterpret_cast<float*>(out + i) = s;
+      else *reinterpret_cast<unsigned short*>(out + i) = f32_to_bf16(s);
+    }
+  }
+  fused_barrier(a, 2);
+  // ---- all-gather: the other ranks' finished shards, all peers' copies interleaved (all links at once)
+  {
+    char* dst = reinterpret_cast<char*>(const_cast<void*>(a.bufs.p[a.rank])) + a.off * (long long)sizeof(T);
+    const long long shard_b = a.shard * (long long)sizeof(T), total_b = a.n * (long long)sizeof(T);
+    const long long nv = shard_b >> 4;
+    for (long long i = tid; i < nv * W; i += stride) {
+      const int j = (int)(i % W);
+      const long long q = i / W;
+      if (j == a.rank) continue;
+      const long long b = (long long)j * shard_b + (q << 4);
+      if (b + 16 <= total_b) {
+        const char* src = reinterpret_cast<const char*>(a.bufs.p[j]) + a.off * (long long)sizeof(T);
+        *reinterpret_cast<u32x4*>(dst + b) = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + b));
+      } else {
+        const char* src = reinterpret_cast<const char*>(a.bufs.p[j]) + a.off * (long long)sizeof(T);
+        for (long long c = b; c < total_b && c < b + 16; ++c) dst[c] = src[c];
+      }
+    }
+  }
+  fused_barrier(a, 3);
+}
+
+template <int W, typename T>
+__global__ __launch_bounds__(kBlock) void p2p_allreduce_fused_kernel(FusedArgs a) {
+  fused_body<W, T>(a);
+}
+
+// Test vehicle: W virtual ranks in ONE launch (blockIdx.y = rank), so that their grids are resident together by
+// construction; each runs the very code of a real rank against its own counters, flags and status word.
+struct VirtualRanks {
+  unsigned* local[kMaxPeers];
+  unsigned* status[kMaxPeers];
+};
+
+template <int W, typename T>
+__global__ __launch_bounds__(kBlock) void p2p_allreduce_fused_virtual_kernel(FusedArgs a, VirtualRanks v) {
+  a.rank = blockIdx.y;
+  a.local = v.local[blockIdx.y];
+  a.status = v.status[blockIdx.y];
+  fused_body<W, T>(a);
+}
+
+template <int W>
+void launch_fused_virtual(const FusedArgs& a, const VirtualRanks& v, int dtype, int blocks, hipStream_t stream) {
+  if (dtype == 0)
+    hipLaunchKernelGGL((p2p_allreduce_fused_virtual_kernel<W, float>), dim3(blocks, W), dim3(kBlock), 0, stream, a, v);
+  else
+    hipLaunchKernelGGL((p2p_allreduce_fused_virtual_kernel<W, unsigned short>), dim3(blocks, W), dim3(kBlock), 0, stream, a, v);
+}
+
+template <int W>
+void launch_fused(const FusedArgs& a, int dtype, int blocks, hipStream_t stream) {
+  if (dtype == 0) hipLaunchKernelGGL((p2p_allreduce_fused_kernel<W, float>), dim3(blocks), dim3(kBlock), 0, stream, a);
+  else hipLaunchKernelGGL((p2p_allreduce_fused_kernel<W, unsigned short>), dim3(blocks), dim3(kBlock), 0, stream, a);
+}
+
+}  // namespace
+
+// The single-launch all-reduce for `world` virtual ranks of one process in one grid (tests): locals[r] / statuses[r]
+// are rank r's counter pair and status word.
+DTF_API int dtf_p2p_allreduce_fused_virtual(const void* const* peers, unsigned* const* flags, int world,
+                                            unsigned* const* locals, unsigned* const* statuses, long long off,
+                                            long long n, int dtype, float scale, unsigned seq, unsigned arrive_base,
+                                            int blocks, int budget_ms, hipStream_t stream) {
+  if (!peers || !flags || !locals || !statuses || world < 1 || world > kMaxPeers) return -1;
+  if ((dtype != 0 && dtype != 1) || off < 0 || blocks < 1 || blocks * world > 256) return -1;
+  if (n <= 0) return 0;
+  const int esz = dtype == 0 ? 4 : 2;
+  FusedArgs a;
+  VirtualRanks v;
+  for (int j = 0; j < kMaxPeers; ++j) {
+    a.bufs.p[j] = j < world ? peers[j] : nullptr;
+    a.flags.p[j] = j < world ? flags[j] : nullptr;
+    v.local[j] = j < world ? locals[j] : nullptr;
+    v.status[j] = j < world ? statuses[j] : nullptr;
+  }
+  for (int j = 0; j < world; ++j)
+    if (!a.bufs.p[j] || !a.flags.p[j] || !v.local[j] || !v.status[j] ||
+        ((uintptr_t)a.bufs.p[j] + (uintptr_t)off * esz) % 16)
+      return -2;
+  const long long q = 16 / esz;
+  const long long per = (n + world - 1) / world;
+  a.shard = (per + q - 1) / q * q;
+  a.local = nullptr; a.status = nullptr; a.off = off; a.n = n; a.scale = scale; a.rank = 0; a.world = world;
+  a.seq = seq; a.arrive_base = arrive_base;
+  a.budget = (long long)(budget_ms < 1 ? 1 : budget_ms) * 100000LL;
+  switch (world) {
+    case 1: launch_fused_virtual<1>(a, v, dtype, blocks, stream); break;
+    case 2: launch_fused_virtual<2>(a, v, dtype, blocks, stream); break;
+    case 3: launch_fused_virtual<3>(a, v, dtype, blocks, stream); break;
+    case 4: launch_fused_virtual<4>(a, v, dtype, blocks, stream); break;
+    case 5: launch_fused_virtual<5>(a, v, dtype, blocks, stream); break;
+    case 6: launch_fused_virtual<6>(a, v, dtype, blocks, stream); break;
+    case 7: launch_fused_virtual<7>(a, v, dtype, blocks, stream); break;
+    default: launch_fused_virtual<8>(a, v, dtype, blocks, stream); break;
+  }
+  return (int)hipGetLastError();
+}
+
+// One-launch direct all-reduce of the region [off, off + n) (elements) of every rank's registered buffer.
+// peers[j]: element 0 of rank j's buffer; flags[j]: rank j's flag array; local: two zero-initialised device words of
+// this rank that persist across calls; seq / arrive_base: sums over the earlier calls of 3 and of 3 * blocks.
+// blocks: grid size, the same on every call of a group (the caller keeps arrive_base consistent with it); it must be
+// small enough to be resident at once (<= 64 is, on a 256-CU device).
+DTF_API int dtf_p2p_allreduce_fused(const void* const* peers, unsigned* const* flags, int world, int rank,
+                                    unsigned* local, unsigned* status, long long off, long long n, int dtype,
+                                    float scale, unsigned seq, unsigned arrive_base, int blocks, int budget_ms,
+                                    hipStream_t stream) {
+  if (!peers || !flags || !local || !status || world < 1 || world > kMaxPeers || rank < 0 || rank >= world) return -1;
+  if ((dtype != 0 && dtype != 1) || off < 0 || blocks < 1 || blocks > 256) return -1;
+  if (n <= 0) return 0;
+  const int esz = dtype == 0 ? 4 : 2;
+  FusedArgs a;
+  for (int j = 0; j < kMaxPeers; ++j) {
+    a.bufs.p[j] = j < world ? peers[j] : nullptr;
+    a.flags.p[j] = j < world ? flags[j] : nullptr;
+  }
+  for (int j = 0; j < world; ++j)
+    if (!a.bufs.p[j] || !a.flags.p[j] || ((uintptr_t)a.bufs.p[j] + (uintptr_t)off * esz) % 16) return -2;
+  const long long q = 16 / esz;
+  const long long per = (n + world - 1) / world;
+  a.shard = (per + q - 1) / q * q;
+  a.local = local; a.status = status; a.off = off; a.n = n; a.scale = scale; a.rank = rank; a.world = world;
+  a.seq = seq; a.arrive_base = arrive_base;
+  a.budget = (long long)(budget_ms < 1 ? 1 : budget_ms) * 100000LL;
+  switch (world) {
+    case 1: launch_fused<1>(a, dtype, blocks, stream); break;
+    case 2: launch_fused<2>(a, dtype, blocks, stream); break;
+    case 3: launch_fused<3>(a, dtype, blocks, stream); break;
+    case 4: launch_fused<4>(a, dtype, blocks, stream); break;
+    case 5: launch_fused<5>(a, dtype, blocks, stream); break;
+    case 6: launch_fused<6>(a, dtype, blocks, stream); break;
+    case 7: launch_fused<7>(a, dtype, blocks, stream); break;
+    default: launch_fused<8>(a, dtype, blocks, stream); break;
+  }
+  return (int)hipGetLastError();
+}

@@ -160,6 +160,25 @@ DTF_API const char* dtf_rccl_error_string(int code) {
   return code < 0 ? "bad argument" : ncclGetErrorString((ncclResult_t)code);
 }
 
+// Sub-communicator by ncclCommSplit: every rank of the parent calls this; ranks with the same colour >= 0 form a
+// group ordered by key, a rank with colour < 0 takes part in the call and gets no communicator (*out = null, 0).
+DTF_API int dtf_rccl_split(void* h, int color, int key, void** out) {
+  if (!h || !out) return -1;
+  RcclComm* p = (RcclComm*)h;
+  ncclComm_t nc = nullptr;
+  const ncclResult_t r = ncclCommSplit(p->comm, color < 0 ? NCCL_SPLIT_NOCOLOR : color, key, &nc, nullptr);
+  *out = nullptr;
+  if (r != ncclSuccess) return (int)r;
+  if (color < 0 || nc == nullptr) return 0;
+  RcclComm* c = new RcclComm();
+  c->comm = nc; c->device = p->device;
+  ncclResult_t q = ncclCommUserRank(nc, &c->rank);
+  if (q == ncclSuccess) q = ncclCommCount(nc, &c->world);
+  if (q != ncclSuccess) { ncclCommDestroy(nc); delete c; return (int)q; }
+  *out = c;
+  return 0;
+}
+
 // Tears the communicator down without waiting for outstanding operations (after a failure).
 DTF_API int dtf_rccl_abort(void* h) {
   if (!h) return -1;

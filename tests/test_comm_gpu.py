@@ -42,14 +42,25 @@ def test_rccl_binding_world1_collectives():
         assert torch.equal(xb, refb) and torch.equal(out, refb) and torch.equal(a2a, refb)
         comm.barrier()
         comm.check_async_error()
+        assert comm.async_error() is None
         assert comm.all_reduce_scalar(3.0) == 3.0
+        # sub-communicator by ncclCommSplit: a working communicator of its own
+        sub = comm.subgroup([0])
+        assert (sub.rank, sub.world) == (0, 1)
+        y = torch.randn(4096, device=_dev())
+        ry = y.clone()
+        sub.all_reduce(y)
+        sub.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(y, ry)
+        sub.shutdown()
     finally:
         comm.shutdown()
 
 
 # ------------------------------------------------------------------- kernels, virtual ranks
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("algorithm", ["direct", "oneshot", "ring", "tree"])
+@pytest.mark.parametrize("algorithm", ["direct", "oneshot", "ring", "tree", "fused"])
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_peer_pointer_kernels_virtual_ranks(algorithm, world, dtype):
     from distributed_tensorflow_amd.comm.ipc import LocalPeers
@@ -58,13 +69,16 @@ def test_peer_pointer_kernels_virtual_ranks(algorithm, world, dtype):
     for n in (8, 1000, 262147):
         bufs = [torch.randn(n, device=_dev()).to(dtype) for _ in range(world)]
         want = sum(b.double() for b in bufs) * 0.25
-        LocalPeers(bufs).all_reduce(algorithm, scale=0.25)
+        peers = LocalPeers(bufs)
+        peers.all_reduce(algorithm, scale=0.25)
         torch.cuda.synchronize()
+        if algorithm == "fused":
+            assert peers.fused_status() == [0] * world      # no barrier of the single-launch kernel timed out
         tol = 1e-5 if dtype == torch.float32 else 0.05 * world ** 0.5
         for r, b in enumerate(bufs):
             assert torch.allclose(b.double(), want, atol=tol, rtol=1e-2 if dtype == torch.bfloat16 else 1e-5), \
                 (algorithm, world, n, r, float((b.double() - want).abs().max()))
-        if algorithm in ("direct", "oneshot"):   # fixed summation order: every rank holds the same bits
+        if algorithm in ("direct", "oneshot", "fused"):   # fixed summation order: every rank holds the same bits
             for b in bufs[1:]:
                 assert torch.equal(b, bufs[0])
 
@@ -100,7 +114,7 @@ def _ipc_worker(rank, world, port, q):
         pg.register(arena)
         res = {}
         for alg, lo, n in (("direct", 0, 300000), ("oneshot", 1024, 4099), ("ring", 8192, 100003),
-                           ("tree", 0, 777), ("auto", 2048, 262144)):
+                           ("tree", 0, 777), ("auto", 2048, 262144), ("fused", 0, 300000), ("fused", 4096, 70003)):
             arena.copy_(mine)
             torch.cuda.synchronize()
             pg.all_reduce(arena[lo:lo + n], alg, scale=1.0 / world, base=arena)
