@@ -97,8 +97,8 @@ struct GemmArgs {
   float drop_scale;      // 1 / (1 - p)
   unsigned long long drop_seed;
   const unsigned long long* drop_off;
-  // optional per-column statistics of the bf16 output for a following batch norm: fp32 [2 * tiles_m][2][N],
-  // row 2 * tile_m + wave_row holds sum(c) and sum(c^2) over that wave's 64 output rows
+  // optional per-column statistics of the bf16 output for a following batch norm: fp32 [tiles_m][2][N],
+  // row tile_m holds sum(c) and sum(c^2) over that tile's 128 output rows
   float* col_stats;
   // stats_mode 1: the output is the gradient dy entering a batch norm whose input was bn_x (laid out like C). The
   // rows then hold sum dy' and sum dy' * (bn_x - mean), dy' = dy masked by the norm's ReLU: bn_relu 0 none,
@@ -760,9 +760,29 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
       cs0[e] = sum_lanes_8_16_32(cs0[e]);
       cs1[e] = sum_lanes_8_16_32(cs1[e]);
     }
+    // ... then the waves of the block that cover the same columns (those stacked along m), through LDS and in
+    // wave order: ONE partial row per 128-row tile, so the buffer and the fold kernel that sums it stay small
+    float* red = reinterpret_cast<float*>(smem);            // [4 waves][2][64 columns]
+    __syncthreads();                                         // every wave is done with its staging area
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wid * 2 + 0) * 64 + lane * 8 + e] = cs0[e];
+        red[(wid * 2 + 1) * 64 + lane * 8 + e] = cs1[e];
+      }
+    }
+    __syncthreads();
     const int n = wn0 + lane * 8;
-    if (lane < 8 && n < g.N) {
-      float* dst = g.col_stats + ((long long)((m0 / BM) * (BM / WTM) + wm) * 2) * g.N + n;
+    if (wm == 0 && lane < 8 && n < g.N) {
+      constexpr int kStep = V ? 1 : 2, kCount = V ? 4 : 2;   // wave ids of the waves below this one
+#pragma unroll
+      for (int q = 1; q < kCount; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          cs0[e] += red[((wid + q * kStep) * 2 + 0) * 64 + lane * 8 + e];
+          cs1[e] += red[((wid + q * kStep) * 2 + 1) * 64 + lane * 8 + e];
+        }
+      float* dst = g.col_stats + ((long long)(m0 / BM) * 2) * g.N + n;
       *reinterpret_cast<f32x4*>(dst) = f32x4{cs0[0], cs0[1], cs0[2], cs0[3]};
       *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs0[4], cs0[5], cs0[6], cs0[7]};
       *reinterpret_cast<f32x4*>(dst + g.N) = f32x4{cs1[0], cs1[1], cs1[2], cs1[3]};
@@ -843,7 +863,7 @@ struct GemmExtra {
   int drop_pad;
   unsigned long long drop_seed;
   const void* drop_off;              // device pointer to the 64-bit Philox offset of this call
-  void* col_stats;                   // optional fp32 [2 * ceil(M / 128)][2][N]: per-wave-row column sums of the output
+  void* col_stats;                   // optional fp32 [ceil(M / 128)][2][N]: per-tile column sums of the output
   int stats_mode, bn_relu;           // see GemmArgs: 1 = statistics of a batch norm's incoming gradient
   const void* bn_x;
   const void* bn_mean;

@@ -299,9 +299,9 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, splits=N
 
 
 def col_stats_rows(M: int, N: int) -> int:
-    """Rows of the column-statistics buffer of an ``M x N`` product: one per wave sub-tile, i.e. two 64-row
-    sub-tiles per 128-row tile, four 32-row ones when the product runs on the 128 x 64 tile."""
-    return (4 if tile_variant(N) else 2) * ((M + 127) // 128)
+    """Rows of the column-statistics buffer of an ``M x N`` product: one per 128-row output tile (the waves of a
+    block combine their sums before they are written)."""
+    return (M + 127) // 128
 
 
 def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int,
@@ -311,7 +311,7 @@ def gemm_raw(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M
     """Unchecked launch on explicit dimensions and leading dimensions (batched attention products,
     implicit-GEMM convolutions). ``add`` is a bf16 tensor laid out like ``out`` that is added to the
     result in the epilogue. ``col_stats`` (fp32 ``[col_stats_rows(M, N), 2, N]``)
-    receives per-wave-row column sums and sums of squares of the bf16 output, the partial statistics of a
+    receives per-tile column sums and sums of squares of the bf16 output, the partial statistics of a
     batch norm that follows. ``in_bn = (scale, shift, relu)`` (fp32 per-channel vectors): the image operand (A of a
     forward product, the activation operand of a weight gradient) is the INPUT of a batch norm and is normalised
     (and rectified) while it is staged, see ``ops.norm.batch_norm_deferred``.

@@ -104,9 +104,15 @@ class SyncPSStrategy(Strategy):
         # ------------------------------------------------------------- pull
         if W > 1:
             with phase("pull"):
+                # every bucket's all-gather is posted before any is waited for: the transfers queue back to back on
+                # the communication stream instead of alternating with host waits
+                works = []
                 for b, (a, e) in zip(self.planner.buckets, self.shards):
-                    self.comm.all_gather(f.master[b.start:b.end], f.master[a:e])
+                    works.append(self.comm.all_gather(f.master[b.start:b.end], f.master[a:e], async_op=True))
                     self.bytes_pulled += (b.numel - (e - a)) * 4
+                for w in works:
+                    if w is not None:
+                        w.wait()
                 f.refresh_shadow()
         self.apply_sparse()
         return loss

@@ -39,7 +39,7 @@ def main():
         x = torch.randn(M, cin, device=DEV).bfloat16()
         w = (torch.randn(cout, cin, device=DEV) * 0.05).bfloat16()
         y = torch.empty(M, cout, device=DEV, dtype=torch.bfloat16)
-        st = torch.empty(gemm.col_stats_rows(M), 2, cout, device=DEV)
+        st = torch.empty(gemm.col_stats_rows(M, cout), 2, cout, device=DEV)
         dx = torch.empty_like(x)
         t_plain = timed(lambda: gemm.gemm_raw(NT, x, w, y, M, cout, cin, cin, cin, cout))
         t_stats = timed(lambda: gemm.gemm_raw(NT, x, w, y, M, cout, cin, cin, cin, cout, col_stats=st))
