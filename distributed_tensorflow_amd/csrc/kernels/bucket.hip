@@ -230,7 +230,7 @@ DTF_API int dtf_bucket_unflatten(int n_tensors, void* const* tensors, const long
 DTF_API int dtf_flat_scale_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype,
                                 const float* scale_ptr, float scale_imm, hipStream_t stream) {
   if (n <= 0) return 0;
-  const int grid = grid_for((n + 7) / 8, kBlock);
+  const int grid = grid_stream((n + 7) / 8, kBlock);
 #define FS(S, D)                                                                                     \
   hipLaunchKernelGGL((flat_scale_cast_kernel<S, D>), dim3(grid), dim3(kBlock), 0, stream, (const S*)src, \
                      (D*)dst, n, scale_ptr, scale_imm)
@@ -252,7 +252,7 @@ DTF_API int dtf_nary_axpy(void* dst, float w_dst, int n_src, const void* const* 
   NaryArgs a;
   a.n_src = n_src;
   for (int i = 0; i < n_src; ++i) { a.src[i] = srcs[i]; a.w[i] = weights[i]; }
-  const int grid = grid_for((n + 7) / 8, kBlock);
+  const int grid = grid_stream((n + 7) / 8, kBlock);
   if (dtype == 0)
     hipLaunchKernelGGL((nary_axpy_kernel<float>), dim3(grid), dim3(kBlock), 0, stream, (float*)dst, a, w_dst, n);
   else

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void col_sum_finish_kernel(const float* __r
 
 DTF_API int dtf_ew_bf16(int op, const void* a, const void* b, void* out, long long n, hipStream_t stream) {
   if (n <= 0) return 0;
-  const int grid = grid_for((n + 7) / 8, kBlock);
+  const int grid = grid_stream((n + 7) / 8, kBlock);
   const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Bp = (const unsigned short*)b;
   unsigned short* O = (unsigned short*)out;
@@ -169,7 +169,7 @@ DTF_API int dtf_ew_drop_bf16(int op, const void* a, const void* b, void* out, lo
                              unsigned long long seed, const void* off, hipStream_t stream) {
   if (n <= 0) return 0;
   if (p < 0.f || p >= 1.f || (p > 0.f && !off)) return -1;
-  const int grid = grid_for((n + 7) / 8, kBlock);
+  const int grid = grid_stream((n + 7) / 8, kBlock);
   const unsigned short* A = (const unsigned short*)a;
   const unsigned short* Bp = (const unsigned short*)b;
   unsigned short* O = (unsigned short*)out;
@@ -250,7 +250,98 @@ DTF_API int dtf_pad_channels_bf16(const void* in, void* out, long long n_pix, in
   if (n_pix <= 0) return 0;
   if (C < 1 || C >= Cp || !(Cp == 4 || Cp % 8 == 0) || (Cp == 4 && (n_pix & 1))) return -1;
   const long long n_chunks = n_pix * Cp / 8;
-  hipLaunchKernelGGL(pad_channels_kernel, dim3(grid_for(n_chunks, kBlock)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(pad_channels_kernel, dim3(grid_stream(n_chunks, kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)in, (unsigned short*)out, n_chunks, C, Cp);
   return (int)hipGetLastError();
+}
+
+// Streaming-copy variants for bandwidth measurements (tools/bench_stream.py): what a memory-bound kernel of this
+// library can expect from HBM, by access pattern. Not used by the training path.
+//   variant 0-3: grid-stride loop over `blocks` blocks; 0 = one 16-byte load and store per iteration, 1 = four loads
+//                in flight, 2 = as 1 with non-temporal stores, 3 = as 1 with non-temporal loads and stores
+//   variant 100 + 10*log2(chunks) + 2*nt_loads + nt_stores: one pass, every thread moves `chunks` 16-byte pieces a
+//                block-width apart and the grid covers the buffer (no loop)
+template <int VARIANT>
+__global__ __launch_bounds__(kBlock) void stream_copy_kernel(const u16x8* __restrict__ src, u16x8* __restrict__ dst,
+                                                             long long n16) {
+  if (VARIANT == 0) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (long long)gridDim.x * kBlock)
+      dst[i] = src[i];
+  } else {
+    const long long stride = (long long)gridDim.x * kBlock;
+    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+      u16x8 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = VARIANT == 3 ? __builtin_nontemporal_load(src + i + k * stride) : src[i + k * stride];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (VARIANT >= 2) __builtin_nontemporal_store(v[k], dst + i + k * stride);
+        else dst[i + k * stride] = v[k];
+      }
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+  }
+}
+
+template <int CHUNKS, bool NTL, bool NTS>
+__global__ __launch_bounds__(kBlock) void stream_onepass_kernel(const u16x8* __restrict__ src, u16x8* __restrict__ dst,
+                                                                long long n16) {
+  const long long base = (long long)blockIdx.x * kBlock * CHUNKS + threadIdx.x;
+  u16x8 v[CHUNKS];
+#pragma unroll
+  for (int k = 0; k < CHUNKS; ++k)
+    if (base + k * kBlock < n16) v[k] = NTL ? __builtin_nontemporal_load(src + base + k * kBlock) : src[base + k * kBlock];
+#pragma unroll
+  for (int k = 0; k < CHUNKS; ++k)
+    if (base + k * kBlock < n16) {
+      if (NTS) __builtin_nontemporal_store(v[k], dst + base + k * kBlock);
+      else dst[base + k * kBlock] = v[k];
+    }
+}
+
+template <int CHUNKS>
+static void onepass_launch(const u16x8* s, u16x8* d, long long n16, int nt, hipStream_t stream) {
+  const unsigned nb = (unsigned)((n16 + kBlock * CHUNKS - 1) / (kBlock * CHUNKS));
+  switch (nt) {
+    case 0: hipLaunchKernelGGL((stream_onepass_kernel<CHUNKS, false, false>), dim3(nb), dim3(kBlock), 0, stream, s, d, n16); break;
+    case 1: hipLaunchKernelGGL((stream_onepass_kernel<CHUNKS, false, true>), dim3(nb), dim3(kBlock), 0, stream, s, d, n16); break;
+    case 2: hipLaunchKernelGGL((stream_onepass_kernel<CHUNKS, true, false>), dim3(nb), dim3(kBlock), 0, stream, s, d, n16); break;
+    default: hipLaunchKernelGGL((stream_onepass_kernel<CHUNKS, true, true>), dim3(nb), dim3(kBlock), 0, stream, s, d, n16); break;
+  }
+}
+
+DTF_API int dtf_stream_copy(const void* src, void* dst, long long bytes, int variant, int blocks, hipStream_t stream) {
+  const long long n16 = bytes / 16;
+  if (n16 <= 0) return 0;
+  const u16x8* s = (const u16x8*)src;
+  u16x8* d = (u16x8*)dst;
+  if (blocks < 1) blocks = kMaxBlocks;
+  if (variant >= 100) {
+    const int lg = (variant - 100) / 10, nt = (variant - 100) % 10;
+    if (nt > 3) return -1;
+    switch (lg) {
+      case 0: onepass_launch<1>(s, d, n16, nt, stream); break;
+      case 1: onepass_launch<2>(s, d, n16, nt, stream); break;
+      case 2: onepass_launch<4>(s, d, n16, nt, stream); break;
+      case 3: onepass_launch<8>(s, d, n16, nt, stream); break;
+      default: return -1;
+    }
+    return (int)hipGetLastError();
+  }
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((stream_copy_kernel<0>), dim3(blocks), dim3(kBlock), 0, stream, s, d, n16); break;
+    case 1: hipLaunchKernelGGL((stream_copy_kernel<1>), dim3(blocks), dim3(kBlock), 0, stream, s, d, n16); break;
+    case 2: hipLaunchKernelGGL((stream_copy_kernel<2>), dim3(blocks), dim3(kBlock), 0, stream, s, d, n16); break;
+    case 3: hipLaunchKernelGGL((stream_copy_kernel<3>), dim3(blocks), dim3(kBlock), 0, stream, s, d, n16); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+// Caps the grid of the streaming kernels (A/B measurements: 2048 restores the looping grid).
+DTF_API int dtf_set_stream_blocks(int blocks) {
+  if (blocks < 1) return -1;
+  stream_block_cap() = blocks;
+  return 0;
 }

@@ -334,7 +334,7 @@ DTF_API int dtf_ew_f32(int op, const float* a, const float* b, float* out, long 
   if (p < 0.f || p >= 1.f || (p > 0.f && !off) || !a || !out || ((op == 0 || op == 1) && !b)) return -1;
   const unsigned thresh = dropout_threshold(p);
   const float sc = p > 0.f ? 1.f / (1.f - p) : scale;
-  const dim3 grid(grid_for((n + 3) / 4, kBlock));
+  const dim3 grid(grid_stream((n + 3) / 4, kBlock));
   const unsigned long long* o = (const unsigned long long*)off;
   switch (op) {
     case 0: hipLaunchKernelGGL((ew_f32_kernel<0>), grid, dim3(kBlock), 0, stream, a, b, out, n, thresh, sc, seed, o); break;

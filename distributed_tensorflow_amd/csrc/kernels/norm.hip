@@ -291,7 +291,7 @@ DTF_API int dtf_bn_fwd_train(const void* x, const void* res, void* y, const floa
                      nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb, gamma, beta,
                      run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
-  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_stream(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
                      (unsigned char*)mask_out, M, C, relu);
   return (int)hipGetLastError();
@@ -342,7 +342,7 @@ DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, cons
   // y == null: the consumer of the normalised activation applies scale / shift (/ ReLU) itself while it stages its
   // operand (gemm.hip, operand transform); only the statistics are finished here
   if (y)
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_stream(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                        (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
                        (unsigned char*)mask_out, M, C, relu);
   return (int)hipGetLastError();
@@ -352,7 +352,7 @@ DTF_API int dtf_bn_fwd_apply(const void* x, const void* res, void* y, const floa
                              long long M, int C, int relu, hipStream_t stream) {
   if (M <= 0 || C <= 0) return 0;
   if (C % 8) return -1;
-  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_stream(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
                      (unsigned char*)nullptr, M, C, relu);
   return (int)hipGetLastError();
@@ -375,7 +375,7 @@ DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float
                      relu);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb, gamma, mean,
                      invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 0);
-  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_stream(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,
                      coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C, relu);
   return (int)hipGetLastError();
@@ -402,7 +402,7 @@ DTF_API int dtf_bn_bwd_stats(const void* x, const void* dy, const void* y, const
   }
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, part, np, gamma,
                      mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 1);
-  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_stream(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,
                      coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C, relu);
   return (int)hipGetLastError();
@@ -769,7 +769,7 @@ DTF_API int dtf_bn_relu_maxpool_fwd(const void* x, void* y, void* idx, const flo
                      nullptr, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb,
                      gamma, beta, run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
-  const int grid = (int)std::min<long long>((long long)N * OH, kMaxBlocks * 4);
+  const int grid = grid_stream((long long)N * OH, 1);
   if (K == 3 && S == 2 && P == 1)
     hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, stream, (const unsigned short*)x, scale,
                        shift, (unsigned short*)y, (unsigned char*)idx, g);
@@ -791,7 +791,7 @@ DTF_API int dtf_bn_relu_maxpool_bwd(const void* x, const void* gy, const void* i
   // one partial row per block of the row-walking reduction; never more than the workspace of the forward holds
   const long long rows = stem ? (long long)N * ((H + 1) / 2) : (long long)N * H;
   const int nb = (int)std::min<long long>(bn_partials_for(M, C), rows);
-  const int grid = (int)std::min<long long>(rows, kMaxBlocks * 4);
+  const int grid = grid_stream(rows, 1);
   const unsigned short *xp = (const unsigned short*)x, *gp = (const unsigned short*)gy;
   const unsigned char* ip = (const unsigned char*)idx;
   if (stem)

@@ -200,7 +200,7 @@ DTF_API int dtf_opt_tick(void* hyper, hipStream_t stream) {
 DTF_API int dtf_adam_apply(void* p, const void* g, void* m, void* v, void* shadow, const void* hyper,
                            long long n, int grad_dtype, int mode, hipStream_t stream) {
   if (n <= 0) return 0;
-  const int grid = grid_for((n + 3) / 4, kBlock);
+  const int grid = grid_stream((n + 3) / 4, kBlock);
   const OptHyper* h = (const OptHyper*)hyper;
 #define LAUNCH(G, S)                                                                              \
   hipLaunchKernelGGL((adam_kernel<G, S>), dim3(grid), dim3(kBlock), 0, stream, (float*)p,         \
@@ -214,7 +214,7 @@ DTF_API int dtf_adam_apply(void* p, const void* g, void* m, void* v, void* shado
 DTF_API int dtf_sgdm_apply(void* p, const void* g, void* vel, void* shadow, const void* hyper,
                            long long n, int grad_dtype, int mode, hipStream_t stream) {
   if (n <= 0) return 0;
-  const int grid = grid_for((n + 3) / 4, kBlock);
+  const int grid = grid_stream((n + 3) / 4, kBlock);
   const OptHyper* h = (const OptHyper*)hyper;
 #define LAUNCH(G, S)                                                                              \
   hipLaunchKernelGGL((sgdm_kernel<G, S>), dim3(grid), dim3(kBlock), 0, stream, (float*)p,         \

@@ -112,7 +112,7 @@ DTF_API int dtf_maxpool_fwd(const void* x, void* y, void* idx, int N, int H, int
   const PoolGeom g = {N, H, W, C, OH, OW, K, S, P};
   if (!geom_ok(g)) return -1;
   const long long total = (long long)N * OH * OW * (C / 8);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_stream(total, kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)x, (unsigned short*)y, (unsigned char*)idx, g);
   return (int)hipGetLastError();
 }
@@ -122,7 +122,7 @@ DTF_API int dtf_maxpool_bwd(const void* gy, const void* idx, void* gx, int N, in
   const PoolGeom g = {N, H, W, C, OH, OW, K, S, P};
   if (!geom_ok(g)) return -1;
   const long long total = (long long)N * H * W * (C / 8);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_stream(total, kBlock)), dim3(kBlock), 0, stream,
                      (const unsigned short*)gy, (const unsigned char*)idx, (unsigned short*)gx, g);
   return (int)hipGetLastError();
 }

@@ -49,6 +49,9 @@ def kernels() -> ctypes.CDLL:
     global _kernels
     if _kernels is None:
         _kernels = _load("libdtf_kernels.so")
+        cap = os.environ.get("DTF_STREAM_BLOCKS")       # A/B switch: grid cap of the streaming kernels
+        if cap:
+            _kernels.dtf_set_stream_blocks(int(cap))
     return _kernels
 
 
