@@ -300,6 +300,16 @@ __global__ __launch_bounds__(kBlock) void stream_onepass_kernel(const u16x8* __r
     }
 }
 
+// One pass with the block index remapped so that each of the 8 XCDs (blocks are dealt to them round-robin) walks its
+// own contiguous eighth of the buffer: the mapping the tiled GEMMs use for L2 locality, here to see what eight
+// separate fronts instead of one cost in DRAM efficiency.
+__global__ __launch_bounds__(kBlock) void stream_xcd_kernel(const u16x8* __restrict__ src, u16x8* __restrict__ dst,
+                                                            long long n16, int per_xcd) {
+  const long long blk = (long long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const long long i = blk * kBlock + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+
 template <int CHUNKS>
 static void onepass_launch(const u16x8* s, u16x8* d, long long n16, int nt, hipStream_t stream) {
   const unsigned nb = (unsigned)((n16 + kBlock * CHUNKS - 1) / (kBlock * CHUNKS));
@@ -317,6 +327,12 @@ DTF_API int dtf_stream_copy(const void* src, void* dst, long long bytes, int var
   const u16x8* s = (const u16x8*)src;
   u16x8* d = (u16x8*)dst;
   if (blocks < 1) blocks = kMaxBlocks;
+  if (variant == 200) {
+    const long long nb = (n16 + kBlock - 1) / kBlock;
+    const int per_xcd = (int)((nb + 7) / 8);
+    hipLaunchKernelGGL(stream_xcd_kernel, dim3(per_xcd * 8), dim3(kBlock), 0, stream, s, d, n16, per_xcd);
+    return (int)hipGetLastError();
+  }
   if (variant >= 100) {
     const int lg = (variant - 100) / 10, nt = (variant - 100) % 10;
     if (nt > 3) return -1;

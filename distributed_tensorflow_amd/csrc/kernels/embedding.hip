@@ -226,17 +226,17 @@ DTF_API int dtf_emb_gather(const void* table, const long long* ids, const void* 
   if (n <= 0) return 0;
   if (table_dtype == 1) {
     if (D % 8 || out_dtype != 1) return -1;
-    hipLaunchKernelGGL((emb_gather_kernel<unsigned short, unsigned short>), dim3(grid_for(n * (D / 8), kBlock)),
+    hipLaunchKernelGGL((emb_gather_kernel<unsigned short, unsigned short>), dim3(grid_stream(n * (D / 8), kBlock)),
                        dim3(kBlock), 0, stream, (const unsigned short*)table, ids, (const unsigned short*)pos, period,
                        (const unsigned short*)typ, tt, (unsigned short*)out, n, D, row_base, n_rows);
   } else {
     if (D % 4) return -1;
     if (out_dtype == 0)
-      hipLaunchKernelGGL((emb_gather_kernel<float, float>), dim3(grid_for(n * (D / 4), kBlock)), dim3(kBlock), 0, stream,
+      hipLaunchKernelGGL((emb_gather_kernel<float, float>), dim3(grid_stream(n * (D / 4), kBlock)), dim3(kBlock), 0, stream,
                          (const float*)table, ids, (const float*)pos, period, (const float*)typ, tt, (float*)out, n, D,
                          row_base, n_rows);
     else
-      hipLaunchKernelGGL((emb_gather_kernel<float, unsigned short>), dim3(grid_for(n * (D / 4), kBlock)), dim3(kBlock), 0,
+      hipLaunchKernelGGL((emb_gather_kernel<float, unsigned short>), dim3(grid_stream(n * (D / 4), kBlock)), dim3(kBlock), 0,
                          stream, (const float*)table, ids, (const float*)pos, period, (const float*)typ, tt,
                          (unsigned short*)out, n, D, row_base, n_rows);
   }
@@ -248,11 +248,11 @@ DTF_API int dtf_emb_scatter_add(const void* g, const long long* ids, float* dtab
   if (n <= 0) return 0;
   if (g_dtype == 1) {
     if (D % 8) return -1;
-    hipLaunchKernelGGL((emb_scatter_add_kernel<unsigned short>), dim3(grid_for(n * (D / 8), kBlock)), dim3(kBlock), 0,
+    hipLaunchKernelGGL((emb_scatter_add_kernel<unsigned short>), dim3(grid_stream(n * (D / 8), kBlock)), dim3(kBlock), 0,
                        stream, (const unsigned short*)g, ids, dtable, n, D, row_base, n_rows, period_rows);
   } else {
     if (D % 4) return -1;
-    hipLaunchKernelGGL((emb_scatter_add_kernel<float>), dim3(grid_for(n * (D / 4), kBlock)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL((emb_scatter_add_kernel<float>), dim3(grid_stream(n * (D / 4), kBlock)), dim3(kBlock), 0, stream,
                        (const float*)g, ids, dtable, n, D, row_base, n_rows, period_rows);
   }
   return (int)hipGetLastError();
@@ -265,11 +265,11 @@ DTF_API int dtf_emb_sorted_grad(const void* g, const long long* sorted_ids, cons
   if (n <= 0) return 0;
   if (g_dtype == 1) {
     if (D % 8) return -1;
-    hipLaunchKernelGGL((emb_sorted_grad_kernel<unsigned short>), dim3(grid_for(n * (D / 8), kBlock)), dim3(kBlock), 0,
+    hipLaunchKernelGGL((emb_sorted_grad_kernel<unsigned short>), dim3(grid_stream(n * (D / 8), kBlock)), dim3(kBlock), 0,
                        stream, (const unsigned short*)g, sorted_ids, perm, dtable, n, D, row_base, n_rows);
   } else {
     if (D % 4) return -1;
-    hipLaunchKernelGGL((emb_sorted_grad_kernel<float>), dim3(grid_for(n * (D / 4), kBlock)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL((emb_sorted_grad_kernel<float>), dim3(grid_stream(n * (D / 4), kBlock)), dim3(kBlock), 0, stream,
                        (const float*)g, sorted_ids, perm, dtable, n, D, row_base, n_rows);
   }
   return (int)hipGetLastError();
@@ -280,11 +280,11 @@ DTF_API int dtf_emb_segment_sum(const void* g, const long long* perm, const long
   if (n_seg <= 0) return 0;
   if (g_dtype == 1) {
     if (D % 8) return -1;
-    hipLaunchKernelGGL((emb_segment_sum_kernel<unsigned short>), dim3(grid_for(n_seg * (D / 8), kBlock)), dim3(kBlock),
+    hipLaunchKernelGGL((emb_segment_sum_kernel<unsigned short>), dim3(grid_stream(n_seg * (D / 8), kBlock)), dim3(kBlock),
                        0, stream, (const unsigned short*)g, perm, seg, out, n_seg, D);
   } else {
     if (D % 4) return -1;
-    hipLaunchKernelGGL((emb_segment_sum_kernel<float>), dim3(grid_for(n_seg * (D / 4), kBlock)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL((emb_segment_sum_kernel<float>), dim3(grid_stream(n_seg * (D / 4), kBlock)), dim3(kBlock), 0, stream,
                        (const float*)g, perm, seg, out, n_seg, D);
   }
   return (int)hipGetLastError();
@@ -295,7 +295,7 @@ DTF_API int dtf_emb_sparse_apply(float* table, float* m, float* v, const float* 
                                  hipStream_t stream) {
   if (n_u <= 0) return 0;
   if (D % 4) return -1;
-  hipLaunchKernelGGL(emb_sparse_apply_kernel, dim3(grid_for(n_u * (D / 4), kBlock)), dim3(kBlock), 0, stream, table, m, v,
+  hipLaunchKernelGGL(emb_sparse_apply_kernel, dim3(grid_stream(n_u * (D / 4), kBlock)), dim3(kBlock), 0, stream, table, m, v,
                      grad, uids, hyper, n_u, D, row_base, n_rows, kind);
   return (int)hipGetLastError();
 }

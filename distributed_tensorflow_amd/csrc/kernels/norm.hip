@@ -187,7 +187,22 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_bwd_kernel(const float* __
   cA[c] = a; cK[c] = -k; c0[c] = mean[c] * k - a * s0 * inv_m;
 }
 
+// The apply kernels: a block covers kBlock * R consecutive 16-byte items in one pass (no block-level loop at the
+// default grid, see grid_stream) and a thread takes R of them a block-width apart, all loads issued before the
+// first use. When C/8 divides the block width every item of a thread lies in the same 8 channels, so the
+// per-channel coefficient vectors (2-3 x 32 bytes against 16 bytes of activation: most of the kernel's cache traffic)
+// are fetched once per thread instead of once per item.
+__device__ __forceinline__ void cvt8(const u16x8& a, float (&o)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(a[i]);
+}
+template <bool NT>
+__device__ __forceinline__ u16x8 ldraw(const unsigned short* p) {
+  return NT ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p)) : *reinterpret_cast<const u16x8*>(p);
+}
+
 // y = act(x*scale + shift (+ res))
+template <int R, bool NT>
 __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(const unsigned short* __restrict__ x,
                                                               const unsigned short* __restrict__ res,
                                                               const float* __restrict__ scale,
@@ -195,36 +210,56 @@ __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(const unsigned sho
                                                               unsigned short* __restrict__ y,
                                                               unsigned char* __restrict__ mask, long long M, int C,
                                                               int relu) {
-  const long long n8 = M * (C >> 3);
-  const long long stride = (long long)gridDim.x * blockDim.x;
   const int c8 = C >> 3;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
-    const int c = (int)(i % c8) << 3;
-    float v[8], a[8], b[8];
-    ld8bf(x + i * 8, v); ld8f(scale + c, a); ld8f(shift + c, b);
+  const long long n8 = M * c8;
+  const bool fixed = (kBlock % c8) == 0;
+  for (long long base = (long long)blockIdx.x * (kBlock * R); base < n8; base += (long long)gridDim.x * (kBlock * R)) {
+    const long long i0 = base + threadIdx.x;
+    u16x8 xr[R], rr[R];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], a[k], b[k]);
-    if (res) {
-      float r[8];
-      ld8bf(res + i * 8, r);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] += r[k];
+    for (int k = 0; k < R; ++k) {
+      const long long i = i0 + k * kBlock;
+      if (i < n8) {
+        xr[k] = ldraw<NT>(x + i * 8);
+        if (res) rr[k] = ldraw<NT>(res + i * 8);
+      }
     }
-    if (mask) {      // sign bits of the pre-activation: the backward pass reads 1 byte instead of 16
-      unsigned mb = 0;
+    float a[8], b[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) mb |= (v[k] > 0.f ? 1u : 0u) << k;
-      mask[i] = (unsigned char)mb;
-    }
-    if (relu) {
+    for (int k = 0; k < R; ++k) {
+      const long long i = i0 + k * kBlock;
+      if (i >= n8) break;
+      if (k == 0 || !fixed) {
+        const int c = (int)(i % c8) << 3;
+        ld8f(scale + c, a); ld8f(shift + c, b);
+      }
+      float v[8];
+      cvt8(xr[k], v);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], a[e], b[e]);
+      if (res) {
+        float r[8];
+        cvt8(rr[k], r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      if (mask) {      // sign bits of the pre-activation: the backward pass reads 1 byte instead of 16
+        unsigned mb = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mb |= (v[e] > 0.f ? 1u : 0u) << e;
+        mask[i] = (unsigned char)mb;
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      st8bf(y + i * 8, v);
     }
-    st8bf(y + i * 8, v);
   }
 }
 
 // dx = A*dy' + K*x + C0 ; dres = dy' (only written when dres != null)
+template <int R, bool NT>
 __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(const unsigned short* __restrict__ x,
                                                               const unsigned short* __restrict__ dy,
                                                               const unsigned short* __restrict__ y,
@@ -235,34 +270,86 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(const unsigned sho
                                                               unsigned short* __restrict__ dx,
                                                               unsigned short* __restrict__ dres, long long M, int C,
                                                               int relu) {
-  const long long n8 = M * (C >> 3);
-  const long long stride = (long long)gridDim.x * blockDim.x;
   const int c8 = C >> 3;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
-    const int c = (int)(i % c8) << 3;
-    float v[8], g[8], a[8], kk[8], z[8];
-    ld8bf(x + i * 8, v); ld8bf(dy + i * 8, g);
-    ld8f(cA + c, a); ld8f(cK + c, kk); ld8f(c0 + c, z);
-    if (relu == 1) {
-      float o[8];
-      ld8bf(y + i * 8, o);
+  const long long n8 = M * c8;
+  const bool fixed = (kBlock % c8) == 0;
+  for (long long base = (long long)blockIdx.x * (kBlock * R); base < n8; base += (long long)gridDim.x * (kBlock * R)) {
+    const long long i0 = base + threadIdx.x;
+    u16x8 xr[R], gr[R], yr[R];
+    unsigned mbits[R];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
-    } else if (relu == 3) {
-      const unsigned mb = reinterpret_cast<const unsigned char*>(y)[i];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) g[k] = (mb >> k) & 1u ? g[k] : 0.f;
-    } else if (relu == 2) {
-      float sa[8], sb[8];
-      ld8f(scale + c, sa); ld8f(shift + c, sb);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) g[k] = fmaf(v[k], sa[k], sb[k]) > 0.f ? g[k] : 0.f;
+    for (int k = 0; k < R; ++k) {
+      const long long i = i0 + k * kBlock;
+      if (i < n8) {
+        xr[k] = ldraw<NT>(x + i * 8);
+        gr[k] = ldraw<NT>(dy + i * 8);
+        if (relu == 1) yr[k] = ldraw<NT>(y + i * 8);
+        else if (relu == 3) mbits[k] = reinterpret_cast<const unsigned char*>(y)[i];
+      }
     }
-    if (dres) st8bf(dres + i * 8, g);
+    float a[8], kk[8], z[8], sa[8], sb[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = fmaf(a[k], g[k], fmaf(kk[k], v[k], z[k]));
-    st8bf(dx + i * 8, v);
+    for (int k = 0; k < R; ++k) {
+      const long long i = i0 + k * kBlock;
+      if (i >= n8) break;
+      if (k == 0 || !fixed) {
+        const int c = (int)(i % c8) << 3;
+        ld8f(cA + c, a); ld8f(cK + c, kk); ld8f(c0 + c, z);
+        if (relu == 2) { ld8f(scale + c, sa); ld8f(shift + c, sb); }
+      }
+      float v[8], g[8];
+      cvt8(xr[k], v); cvt8(gr[k], g);
+      if (relu == 1) {
+        float o[8];
+        cvt8(yr[k], o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+      } else if (relu == 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (mbits[k] >> e) & 1u ? g[e] : 0.f;
+      } else if (relu == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = fmaf(v[e], sa[e], sb[e]) > 0.f ? g[e] : 0.f;
+      }
+      if (dres) st8bf(dres + i * 8, g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(a[e], g[e], fmaf(kk[e], v[e], z[e]));
+      st8bf(dx + i * 8, v);
+    }
   }
+}
+
+static int g_apply_rows = 2;   // items per thread of the apply kernels: 1, 2 or 4
+static int g_apply_nt = 1;     // non-temporal activation loads
+
+DTF_API int dtf_set_bn_apply_rows(int r, int nt) {
+  if (r != 1 && r != 2 && r != 4) return -1;
+  g_apply_rows = r;
+  g_apply_nt = nt != 0;
+  return 0;
+}
+
+static void launch_apply_fwd(const void* x, const void* res, const float* scale, const float* shift, void* y,
+                             void* mask, long long M, int C, int relu, hipStream_t stream) {
+#define AF(R, NT)                                                                                                       \
+  hipLaunchKernelGGL((bn_apply_fwd_kernel<R, NT>), dim3(grid_stream(M * (C / 8), kBlock * R)), dim3(kBlock), 0, stream, \
+                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,       \
+                     (unsigned char*)mask, M, C, relu)
+  if (g_apply_nt) { if (g_apply_rows == 4) AF(4, true); else if (g_apply_rows == 2) AF(2, true); else AF(1, true); }
+  else { if (g_apply_rows == 4) AF(4, false); else if (g_apply_rows == 2) AF(2, false); else AF(1, false); }
+#undef AF
+}
+
+static void launch_apply_bwd(const void* x, const void* dy, const void* y, const float* coef, const float* scale,
+                             const float* shift, void* dx, void* dres, long long M, int C, int relu,
+                             hipStream_t stream) {
+#define AB(R, NT)                                                                                                       \
+  hipLaunchKernelGGL((bn_apply_bwd_kernel<R, NT>), dim3(grid_stream(M * (C / 8), kBlock * R)), dim3(kBlock), 0, stream, \
+                     (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C, \
+                     coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C, relu)
+  if (g_apply_nt) { if (g_apply_rows == 4) AB(4, true); else if (g_apply_rows == 2) AB(2, true); else AB(1, true); }
+  else { if (g_apply_rows == 4) AB(4, false); else if (g_apply_rows == 2) AB(2, false); else AB(1, false); }
+#undef AB
 }
 
 static int bn_partials_for(long long M, int C) {
@@ -291,9 +378,7 @@ DTF_API int dtf_bn_fwd_train(const void* x, const void* res, void* y, const floa
                      nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb, gamma, beta,
                      run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
-  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_stream(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
-                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
-                     (unsigned char*)mask_out, M, C, relu);
+  launch_apply_fwd(x, res, scale, shift, y, mask_out, M, C, relu, stream);
   return (int)hipGetLastError();
 }
 
@@ -342,9 +427,7 @@ DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, cons
   // y == null: the consumer of the normalised activation applies scale / shift (/ ReLU) itself while it stages its
   // operand (gemm.hip, operand transform); only the statistics are finished here
   if (y)
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_stream(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
-                       (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
-                       (unsigned char*)mask_out, M, C, relu);
+    launch_apply_fwd(x, res, scale, shift, y, mask_out, M, C, relu, stream);
   return (int)hipGetLastError();
 }
 
@@ -352,9 +435,7 @@ DTF_API int dtf_bn_fwd_apply(const void* x, const void* res, void* y, const floa
                              long long M, int C, int relu, hipStream_t stream) {
   if (M <= 0 || C <= 0) return 0;
   if (C % 8) return -1;
-  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_stream(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
-                     (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,
-                     (unsigned char*)nullptr, M, C, relu);
+  launch_apply_fwd(x, res, scale, shift, y, nullptr, M, C, relu, stream);
   return (int)hipGetLastError();
 }
 
@@ -375,9 +456,7 @@ DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float
                      relu);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb, gamma, mean,
                      invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 0);
-  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_stream(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
-                     (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,
-                     coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C, relu);
+  launch_apply_bwd(x, dy, y, coef, scale, shift, dx, dres, M, C, relu, stream);
   return (int)hipGetLastError();
 }
 
@@ -402,9 +481,7 @@ DTF_API int dtf_bn_bwd_stats(const void* x, const void* dy, const void* y, const
   }
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, part, np, gamma,
                      mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 1);
-  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_stream(M * (C / 8), kBlock)), dim3(kBlock), 0, stream,
-                     (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C,
-                     coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C, relu);
+  launch_apply_bwd(x, dy, y, coef, scale, shift, dx, dres, M, C, relu, stream);
   return (int)hipGetLastError();
 }
 

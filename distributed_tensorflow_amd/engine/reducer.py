@@ -13,10 +13,12 @@ centralized/client.py:83-90).
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Any, Callable
 
 import torch
 
+from ..ops import _lib
 from ..ops import bucket as bops
 from .flat import Bucket, BucketPlanner, FlatParams
 
@@ -34,6 +36,7 @@ class GradReducer:
         self.works: list[Any] = []
         self.enabled = True
         self._in_step = False
+        self._plans: dict = {}
 
     # ----------------------------------------------------------------- hooks
     def attach(self) -> None:
@@ -76,27 +79,59 @@ class GradReducer:
             self._next += 1
 
     # ------------------------------------------------------------------ pack
+    def _plan(self, b: Bucket, dtype: torch.dtype):
+        """The step-invariant half of a bucket's pack call (offset and length tables, dtype codes), built once per
+        (bucket, gradient dtype); only the pointer table changes from step to step."""
+        key = (b.index, dtype)
+        plan = self._plans.get(key)
+        if plan is None:
+            n = len(b.slots)
+            plan = (n, (ctypes.c_longlong * n)(*[s.offset for s in b.slots]),
+                    (ctypes.c_longlong * n)(*[s.numel for s in b.slots]), (ctypes.c_void_p * n)(),
+                    _lib.dtype_code(dtype), _lib.dtype_code(self.flat.grad.dtype),
+                    [tuple(s.stride) for s in b.slots])
+            self._plans[key] = plan
+        return plan
+
     @torch.no_grad()
     def _pack(self, b: Bucket) -> None:
         flat = self.flat
+        grads = [s.param.grad for s in b.slots]
+        g0 = grads[0]
+        if flat.grad.is_cuda and g0 is not None and all(g is not None and g.dtype == g0.dtype for g in grads):
+            # fast path (every step of an ordinary run): all gradients present, one dtype
+            n, offs, nums, ptrs, src_code, dst_code, strides = self._plan(b, g0.dtype)
+            for k, g in enumerate(grads):
+                if g.stride() != strides[k]:
+                    g = self._like_param(g, b.slots[k])
+                    grads[k] = g
+                ptrs[k] = g.data_ptr()
+            rc = _lib.kernels().dtf_bucket_flatten(n, ptrs, offs, nums, _lib.ptr(flat.grad), src_code, dst_code, None,
+                                                   ctypes.c_float(self.grad_scale), _lib.stream_ptr(flat.device))
+            _lib.check(rc, "bucket_flatten")
+            for s in b.slots:
+                s.param.grad = None
+            return
         groups: dict[torch.dtype, tuple[list, list]] = {}
-        missing = []
-        for s in b.slots:
-            g = s.param.grad
-            if g is None:
-                missing.append(s)
+        for s, g in zip(b.slots, grads):
+            if g is None:            # parameter took no part in this step
+                flat.grad[s.offset:s.offset + s.numel].zero_()
                 continue
-            if any(gs != ss for gs, ss, n in zip(g.stride(), s.stride, s.shape) if n != 1):
-                g = torch.empty_strided(tuple(s.shape), s.stride, dtype=g.dtype, device=g.device).copy_(g)
+            g = self._like_param(g, s)
             ts, offs = groups.setdefault(g.dtype, ([], []))
-            ts.append(g)
+            ts.append(g.as_strided((g.numel(),), (1,)))
             offs.append(s.offset)
             s.param.grad = None
-        for s in missing:  # parameter took no part in this step
-            flat.grad[s.offset:s.offset + s.numel].zero_()
-        for dt, (ts, offs) in groups.items():
+        for ts, offs in groups.values():
             # every gradient is a dense block laid out like its parameter: pack its raw memory order
-            bops.flatten([t.as_strided((t.numel(),), (1,)) for t in ts], flat.grad, offs, scale=self.grad_scale)
+            bops.flatten(ts, flat.grad, offs, scale=self.grad_scale)
+
+    @staticmethod
+    def _like_param(g: torch.Tensor, s) -> torch.Tensor:
+        """``g`` in the memory order of its parameter (strides of size-1 dimensions do not matter)."""
+        if any(gs != ss for gs, ss, n in zip(g.stride(), s.stride, s.shape) if n != 1):
+            return torch.empty_strided(tuple(s.shape), s.stride, dtype=g.dtype, device=g.device).copy_(g)
+        return g
 
     # ---------------------------------------------------------------- finish
     def finish(self) -> list[Any]:

@@ -52,6 +52,10 @@ def kernels() -> ctypes.CDLL:
         cap = os.environ.get("DTF_STREAM_BLOCKS")       # A/B switch: grid cap of the streaming kernels
         if cap:
             _kernels.dtf_set_stream_blocks(int(cap))
+        rows = os.environ.get("DTF_BN_APPLY")           # A/B switch "rows,nt": items per thread of the batch-norm
+        if rows:                                        # apply kernels, non-temporal loads on / off
+            r, nt = rows.split(",")
+            _kernels.dtf_set_bn_apply_rows(int(r), int(nt))
     return _kernels
 
 

@@ -49,6 +49,7 @@ def main():
         for nt in range(4):
             run(100 + 10 * lg + nt, 0, f"one pass, {1 << lg} x 16 B per thread, non-temporal "
                                        f"{('none', 'stores', 'loads', 'loads+stores')[nt]}")
+    run(200, 0, "one pass, 1 x 16 B per thread, one contiguous eighth per XCD")
     t = timeit(lambda: dst.copy_(src))
     lines.append(f"copy  torch tensor.copy_ {'':35s}: {2 * nbytes / t / 1e12:5.2f} TB/s")
     t = timeit(lambda: dst.zero_())

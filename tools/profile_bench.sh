@@ -14,7 +14,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 with open(sys.argv[2], "w") as f:
-    f.write(f"total kernel time {tot/1e6:.2f} ms over the whole run (7 steps)\n")
+    f.write(f"total kernel time {tot/1e6:.2f} ms over the whole run (warm-up, timed and phase-timing steps: see calls / kernels per step)\n")
     f.write(f"{'pct':>6} {'total_ms':>10} {'calls':>7} {'avg_us':>9}  name\n")
     for r in rows[:60]:
         f.write(f"{100*float(r['TotalDurationNs'])/tot:6.2f} {float(r['TotalDurationNs'])/1e6:10.3f} {int(r['Calls']):7d} {float(r['AverageNs'])/1e3:9.1f}  {r['Name'][:150]}\n")
