@@ -45,10 +45,7 @@ template <> struct Vec8<unsigned short> {
     for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(a[i]);
   }
   static __device__ __forceinline__ void store(unsigned short* p, const float (&o)[8]) {
-    u16x8 a;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = f32_to_bf16(o[i]);
-    *reinterpret_cast<u16x8*>(p) = a;
+    store8_bf16(p, o);
   }
   static __device__ __forceinline__ float ld1(const unsigned short* p) { return bf16_to_f32(*p); }
   static __device__ __forceinline__ void st1(unsigned short* p, float v) { *p = f32_to_bf16(v); }

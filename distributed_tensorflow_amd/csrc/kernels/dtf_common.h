@@ -42,6 +42,27 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   return *reinterpret_cast<unsigned short*>(&b);
 }
 
+// Two floats to one packed bf16 pair (lo in bits 0-15) with ONE v_cvt_pk_bf16_f32; converting the halves separately
+// costs two converts, a shift and an or.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// Eight (four) floats to consecutive bf16 values at a 16-byte (8-byte) aligned address.
+__device__ __forceinline__ void store8_bf16(unsigned short* p, const float (&o)[8]) {
+  const u32x4_t a = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+  *reinterpret_cast<u32x4_t*>(p) = a;
+}
+__device__ __forceinline__ void store4_bf16(unsigned short* p, float a, float b, float c, float d) {
+  const u32x2_t v = {pack_bf16x2(a, b), pack_bf16x2(c, d)};
+  *reinterpret_cast<u32x2_t*>(p) = v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

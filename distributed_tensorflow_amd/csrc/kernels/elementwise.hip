@@ -11,10 +11,7 @@ __device__ __forceinline__ void ld8(const unsigned short* p, float (&o)[8]) {
   for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(a[i]);
 }
 __device__ __forceinline__ void st8(unsigned short* p, const float (&o)[8]) {
-  u16x8 a;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = f32_to_bf16(o[i]);
-  *reinterpret_cast<u16x8*>(p) = a;
+  store8_bf16(p, o);
 }
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }

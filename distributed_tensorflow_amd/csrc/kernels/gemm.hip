@@ -51,6 +51,7 @@
 // channel counts that are multiples of 8 elements; M and K are otherwise free (edges are
 // zero-filled / masked).
 #include "dtf_common.h"
+#include <type_traits>
 
 using namespace dtf;
 
@@ -121,6 +122,7 @@ struct GemmArgs {
   const float* tf_scale;
   const float* tf_shift;
   int tf_relu;
+  int tn_shift;      // log2(tiles_n) when tiles_n is a power of two, else -1
   ConvGeom cv;
 };
 
@@ -132,19 +134,32 @@ __device__ __forceinline__ void divmod(int x, int d, float rcp, int& q, int& r) 
   else if (r >= d) { ++q; r -= d; }
 }
 
-// v summed over the 8 lanes {lane ^ 8, lane ^ 16, lane ^ 32 and their combinations}, without a trip through LDS:
-// a DPP rotation inside the 16-lane row, then the gfx950 row / half swaps (swapping a value with itself returns
-// {rows 0,0,2,2 | rows 1,1,3,3} and {lower half twice | upper half twice}).
-__device__ __forceinline__ float sum_lanes_8_16_32(float v) {
+// Sixteen per-lane values (c0[0..7], c1[0..7]) summed over the 8 lanes {lane ^ 8, lane ^ 16, lane ^ 32 and their
+// combinations}, without a trip through LDS and without computing every total in every lane: a DPP rotation inside
+// the 16-lane row, then the gfx950 row swap (v_permlane16_swap exchanges the odd rows of its first operand with the
+// even rows of its second: swapping c0[e] with c1[e] and adding leaves the total of c0[e] in the even rows and that
+// of c1[e] in the odd rows, one swap and one add for two values), then the half swap the same way. A lane ends up
+// with out[0..3] = totals of statistic (lane >> 4) & 1, elements 4 h .. 4 h + 3, h = lane >> 5. Each total is
+// ((v + v[lane ^ 8]) + the same of lane ^ 16) + the same of lane ^ 32: a fixed order.
+__device__ __forceinline__ void sum16_lanes_8_16_32(float (&c0)[8], float (&c1)[8], float (&out)[4]) {
   typedef unsigned int u32x2_s __attribute__((ext_vector_type(2)));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
-  unsigned u = __float_as_uint(v);
-  const u32x2_s a = __builtin_bit_cast(u32x2_s, __builtin_amdgcn_permlane16_swap(u, u, false, false));
-  const unsigned a0 = a[0], a1 = a[1];
-  u = __float_as_uint(__uint_as_float(a0) + __uint_as_float(a1));
-  const u32x2_s b = __builtin_bit_cast(u32x2_s, __builtin_amdgcn_permlane32_swap(u, u, false, false));
-  const unsigned b0 = b[0], b1 = b[1];
-  return __uint_as_float(b0) + __uint_as_float(b1);
+  float h[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    c0[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c0[e]), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    c1[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c1[e]), 0x128, 0xf, 0xf, false));
+    const u32x2_s a = __builtin_bit_cast(
+        u32x2_s, __builtin_amdgcn_permlane16_swap(__float_as_uint(c0[e]), __float_as_uint(c1[e]), false, false));
+    const unsigned a0 = a[0], a1 = a[1];
+    h[e] = __uint_as_float(a0) + __uint_as_float(a1);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const u32x2_s b = __builtin_bit_cast(
+        u32x2_s, __builtin_amdgcn_permlane32_swap(__float_as_uint(h[e]), __float_as_uint(h[e + 4]), false, false));
+    const unsigned b0 = b[0], b1 = b[1];
+    out[e] = __uint_as_float(b0) + __uint_as_float(b1);
+  }
 }
 
 __device__ __forceinline__ int swz_off(int row, int chunk) {
@@ -353,7 +368,7 @@ struct Stager {
         float lo = fmaf(__uint_as_float(v[e] << 16), sc[2 * e], sh[2 * e]);
         float hi = fmaf(__uint_as_float(v[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]);
         if (g.tf_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-        v[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+        v[e] = pack_bf16x2(lo, hi);
       }
       const bool ok = (okmask >> i) & 1u;
       r[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
@@ -404,8 +419,15 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 // V selects the output tile: 0 = 128 x 128 (waves 2 x 2, 64 x 64 each), 1 = 128 x 64 (waves 4 x 1, 32 x 64 each) for
 // products at most 64 columns wide (the 64-channel layers of a ResNet, a convolution stem): half the accumulators,
 // half the B tile, four resident blocks per CU instead of three.
-template <int A_T, int B_T, int CONV, int STAGES, int V, int TF = 0>
-__global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs g) {
+// EPI != 0: a lean store phase. Bit 0 marks it: no split-K slab, bias, activation, dropout, fp32 output or up2
+// placement is compiled in. The other bits say what IS compiled in, unconditionally: 2 = column statistics of the
+// output (stats_mode 0), 4 = the accumulate input C_in (its mask stays a run-time test), 8 = the sums of a batch
+// norm's backward pass (stats_mode 1). The host launches the variant that matches the request exactly. The general
+// store phase (EPI 0) tests every feature per accumulator group and per pass at run time; for the short-contraction
+// products of the 1x1 convolutions, whose blocks live a few microseconds, those hundreds of untaken branches were
+// 11-13 % of the kernel.
+template <int A_T, int B_T, int CONV, int STAGES, int V, int TF = 0, int EPI = 0>
+__global__ __launch_bounds__(kThreads, V ? 4 : 3) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES x (A tile, B tile)
   constexpr int BN_ = V ? 64 : 128;          // tile columns
   constexpr int WTM = V ? 32 : 64;           // rows of a wave's sub-tile
@@ -423,8 +445,8 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
   const int vt = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
   const int tile = vt / ntaps;
   const int tap = vt - tile * ntaps;
-  int tm = tile / g.tiles_n;
-  const int tn = tile % g.tiles_n;
+  int tm = g.tn_shift >= 0 ? tile >> g.tn_shift : tile / g.tiles_n;   // tiles_n is a power of two in most launches
+  const int tn = tile - tm * g.tiles_n;
   // Strided data gradient: rows are ordered by parity class and the classes do unequal work (a class
   // is reached by 0..4 of the filter taps), while an XCD owns a contiguous range of tiles. Deal the
   // row tiles of the four classes out round-robin so that every XCD gets the same mix.
@@ -433,7 +455,8 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
   const int split = blockIdx.y;
   const int plane = CONV == 3 ? tap : (int)blockIdx.z;
   const int planes = CONV == 3 ? ntaps : (int)gridDim.z;
-  const int b1 = plane / g.nb2, b2 = plane - b1 * g.nb2;
+  // lean variants are launched for a single plane only
+  const int b1 = EPI ? 0 : plane / g.nb2, b2 = EPI ? 0 : plane - b1 * g.nb2;
   const unsigned short* Ap = g.A + b1 * g.sA1 + b2 * g.sA2;
   const unsigned short* Bp = g.B + b1 * g.sB1 + b2 * g.sB2;
   const long long c_off = b1 * g.sC1 + b2 * g.sC2;
@@ -445,11 +468,16 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
   const int wm = V ? wid : wid >> 1, wn = V ? 0 : wid & 1;
   const int fr = lane & 15, fq = lane >> 4;
 
+  // Lean variants (always at least one k-tile) start the accumulators with the first tile's first MFMA, whose
+  // addend is then the constant zero: 16 * MI register clears fewer per wave.
+  constexpr bool kPeelZero = EPI != 0 && STAGES == 1;
   f32x4 acc[MI][4];
+  if (!kPeelZero) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   constexpr int GA = CONV == 1 ? 1 : CONV == 2 ? 2 : CONV == 4 ? 3 : 0;
   constexpr int GB = CONV == 2 ? 4 : CONV == 3 ? 3 : 0;
@@ -481,7 +509,8 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
     return t;
   };
 
-  auto compute = [&](const char* la) {
+  auto compute = [&](const char* la, auto first_tag) {
+    constexpr bool kFirst = decltype(first_tag)::value;
     const char* lb = la + kTileBytes;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -495,9 +524,12 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           // swapped operands: result register r of lane l is C[m = i*16 + (l&15)][n = j*16 + (l>>4)*4 + r]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              b[j], a[i], kFirst && ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0);
     }
   };
+  using Yes = std::true_type;
+  using No = std::false_type;
 
   int t = next_tile(0);
   if (STAGES == 2) {
@@ -518,7 +550,7 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
         sa.load(g, Ap, g.lda, g.M, m0, k0, kend, tap);
         sb.load(g, Bp, g.ldb, g.N, n0, k0, kend, tap);
       }
-      compute(smem + cur * kStage);
+      compute(smem + cur * kStage, No{});
       if (more) {
         char* na = smem + (cur ^ 1) * kStage;
         sa.store(na);
@@ -536,6 +568,7 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
       sa.load(g, Ap, g.lda, g.M, m0, kbeg + t * BK, kend, tap);
       sb.load(g, Bp, g.ldb, g.N, n0, kbeg + t * BK, kend, tap);
     }
+    bool first = kPeelZero;
     while (t < nt) {
       if (TF == 1) sa.transform(g);
       if (TF == 2) sb.transform(g);
@@ -548,7 +581,12 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
         sa.load(g, Ap, g.lda, g.M, m0, k0, kend, tap);
         sb.load(g, Bp, g.ldb, g.N, n0, k0, kend, tap);
       }
-      compute(smem);
+      if (kPeelZero && first) {
+        compute(smem, Yes{});
+        first = false;
+      } else {
+        compute(smem, No{});
+      }
       __syncthreads();
       t = tnext;
     }
@@ -556,7 +594,7 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
 
   // ---- epilogue ---------------------------------------------------------------------
   const int wm0 = m0 + wm * WTM, wn0 = n0 + wn * 64;
-  if (g.splits > 1) {
+  if (!EPI && g.splits > 1) {
     // fp32 partial slab [split][batch][M][N]; 16 bytes per lane, 4 consecutive n
     float* W = reinterpret_cast<float*>(g.C) + ((long long)split * planes + plane) * g.M * g.N;
 #pragma unroll
@@ -574,7 +612,7 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
 
   // bias + activation in registers
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < (EPI ? 0 : 4); ++j) {
     const int n = wn0 + j * 16 + fq * 4;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && n < g.N) {
@@ -596,7 +634,7 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
         acc[i][j][r] = v;
       }
   }
-  if (g.drop_thresh) {
+  if (!EPI && g.drop_thresh) {
     const unsigned long long off = *g.drop_off;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -612,7 +650,7 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
     }
   }
 
-  if (g.out_fp32) {
+  if (!EPI && g.out_fp32) {
     float* C = reinterpret_cast<float*>(g.C) + c_off;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -636,15 +674,19 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       u32x2 o;
-      o[0] = (unsigned)f32_to_bf16(acc[i][j][0]) | ((unsigned)f32_to_bf16(acc[i][j][1]) << 16);
-      o[1] = (unsigned)f32_to_bf16(acc[i][j][2]) | ((unsigned)f32_to_bf16(acc[i][j][3]) << 16);
+      o[0] = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+      o[1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
       const int cb = j * 32 + fq * 8;  // byte column inside the 128-byte row
       *reinterpret_cast<u32x2*>(stage + swz_off(row, cb >> 4) + (cb & 8)) = o;
     }
   }
   __syncthreads();
   unsigned short* C = reinterpret_cast<unsigned short*>(g.C) + c_off;
-  const unsigned short* Cin = g.Cin ? g.Cin + c_off : nullptr;
+  constexpr bool kLean = EPI != 0;
+  const bool has_cin = kLean ? (EPI & 4) != 0 : g.Cin != nullptr;
+  const bool stats0 = kLean ? (EPI & 2) != 0 : (g.col_stats && g.stats_mode == 0);
+  const bool bn_grad_stats = kLean ? (EPI & 8) != 0 : (g.col_stats && g.stats_mode == 1);
+  const unsigned short* Cin = has_cin ? g.Cin + c_off : nullptr;
   // Column statistics for the batch norm that follows (the accumulators are dead by now, so these 16
   // registers do not raise the kernel's peak): a lane sees 8 of its wave's 64 rows for one 8-column chunk.
   float cs0[8], cs1[8];
@@ -652,7 +694,7 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
   for (int e = 0; e < 8; ++e) { cs0[e] = 0.f; cs1[e] = 0.f; }
   // per-channel constants of the lane's fixed 8-column chunk (batch-norm backward statistics only)
   float bmu[8], bsa[8], bsb[8];
-  if (g.col_stats && g.stats_mode == 1) {
+  if (bn_grad_stats) {
     const int n = wn0 + (lane & 7) * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -662,34 +704,81 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
       bsb[e] = in && g.bn_relu == 2 ? g.bn_shift[n + e] : 0.f;
     }
   }
-  // ... and the norm's input (and mask bytes), fetched four passes at a time so that their latency is paid twice
-  // per tile rather than per pass (all eight at once would cost the kernel its third resident block)
+  // The lane's chunk of pass p: row wm0 + row0 + 8 p of the output, columns n .. n + 7.
+  constexpr int kPasses = WTM / 8;           // 64 lanes x 16 bytes = 8 rows of the sub-tile per pass
+  const int row0 = lane >> 3, chunk = lane & 7;
+  const int n = wn0 + chunk * 8;
+  const bool n_ok = n < g.N;
+  const bool full_m = wm0 + WTM <= g.M;      // uniform: no row of the wave's sub-tile is past the edge
+  const bool remap = (CONV == 2 && g.cv.S == 2) || (CONV == 0 && !EPI && g.up2);
+  auto row_ok = [&](int p) { return full_m || wm0 + row0 + 8 * p < g.M; };
+  // lean variants step a precomputed 64-bit offset from pass to pass; the general kernel, short of registers,
+  // multiplies afresh
+  const long long off0 = kLean ? (long long)(wm0 + row0) * g.ldc + n : 0, step = kLean ? 8LL * g.ldc : 0;
+  auto linear_off = [&](int p) { return kLean ? off0 + p * step : (long long)(wm0 + row0 + 8 * p) * g.ldc + n; };
+  auto elem_off = [&](int p) -> long long {  // elements from C (and C_in) to that chunk
+    if (!remap) return linear_off(p);
+    const int m = wm0 + row0 + 8 * p;
+    long long mr;
+    if (CONV == 2) {                         // class-ordered GEMM row -> pixel row in memory
+      int pn, ph, pw;
+      dgrad_pixel(g.cv, m, pn, ph, pw);
+      mr = ((long long)pn * g.cv.H + ph) * g.cv.W + pw;
+    } else {                                 // up2: the even pixel of the 2x2 patch the row stands for
+      int pn, rem, a, b;
+      divmod(m, (g.cv.H >> 1) * (g.cv.W >> 1), 4.f * g.cv.r_hw, pn, rem);
+      divmod(rem, g.cv.W >> 1, 2.f * g.cv.r_w, a, b);
+      mr = ((long long)pn * g.cv.H + 2 * a) * g.cv.W + 2 * b;
+    }
+    return mr * g.ldc + n;
+  };
+  // Lean variants request everything the passes read before the first of them runs, so that a tile pays each
+  // latency once: the accumulate input (global), the norm's input and mask bytes of the first four passes (global;
+  // all eight would cost the kernel its third resident block), then the staged rows (LDS). The accumulators are
+  // dead by now and their registers take the data. The general kernel, whose run-time feature tests keep more
+  // alive, fetches pass by pass (it would lose a resident block to the extra registers).
+  constexpr int kAhead = kLean ? kPasses : 1;
+  u32x4 cin[kAhead];
+  unsigned cin_keep[kAhead];
+  auto fetch_cin = [&](int p, u32x4& c, unsigned& keep) {
+    c = u32x4{0u, 0u, 0u, 0u};
+    keep = 0xffu;
+    if (row_ok(p) && n_ok) {
+      const long long at = elem_off(p);
+      c = *reinterpret_cast<const u32x4*>(Cin + at);
+      if (g.cin_mask) keep = g.cin_mask[(c_off + at) >> 3];
+    }
+  };
+  if (kLean && has_cin) {
+#pragma unroll
+    for (int p = 0; p < kAhead; ++p) fetch_cin(p, cin[p], cin_keep[p]);
+  }
   u32x4 bxv[4];
   unsigned bkeep[4];
   auto fetch_bn = [&](int p0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int id = lane + 64 * (p0 + q);
-      const int m = wm0 + (id >> 3), n = wn0 + (id & 7) * 8;
       bxv[q] = u32x4{0u, 0u, 0u, 0u};
       bkeep[q] = 0xffu;
-      if (m < g.M && n < g.N) {
-        const long long at = c_off + (long long)m * g.ldc + n;
+      if (row_ok(p0 + q) && n_ok) {
+        const long long at = c_off + linear_off(p0 + q);
         bxv[q] = *reinterpret_cast<const u32x4*>(g.bn_x + at);
         if (g.bn_relu == 3) bkeep[q] = g.bn_mask[at >> 3];
       }
     }
   };
-  const bool bn_grad_stats = g.col_stats && g.stats_mode == 1;
   if (bn_grad_stats) fetch_bn(0);
-  constexpr int kPasses = WTM / 8;           // 64 lanes x 16 bytes = 8 rows of the sub-tile per pass
+  u32x4 staged[kAhead];
+  if (kLean) {
+#pragma unroll
+    for (int p = 0; p < kAhead; ++p)
+      staged[p] = *reinterpret_cast<const u32x4*>(stage + swz_off(row0 + 8 * p, chunk));
+  }
 #pragma unroll
   for (int p = 0; p < kPasses; ++p) {
-    const int id = lane + 64 * p;
-    const int row = id >> 3, chunk = id & 7;
-    const int m = wm0 + row, n = wn0 + chunk * 8;
-    u32x4 v = *reinterpret_cast<const u32x4*>(stage + swz_off(row, chunk));
-    if (g.col_stats && g.stats_mode == 0 && m < g.M) {
+    u32x4 v = kLean ? staged[p % kAhead] : *reinterpret_cast<const u32x4*>(stage + swz_off(row0 + 8 * p, chunk));
+    const bool m_ok = row_ok(p);
+    if (stats0 && m_ok) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
@@ -697,28 +786,21 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
         cs0[2 * e + 1] += hi; cs1[2 * e + 1] = fmaf(hi, hi, cs1[2 * e + 1]);
       }
     }
-    if (m < g.M && n < g.N) {
-      long long mr = m;
-      if (CONV == 2 && g.cv.S == 2) {       // class-ordered GEMM row -> pixel row in memory
-        int pn, ph, pw;
-        dgrad_pixel(g.cv, m, pn, ph, pw);
-        mr = ((long long)pn * g.cv.H + ph) * g.cv.W + pw;
-      } else if (CONV == 0 && g.up2) {
-        int pn, rem, a, b;
-        divmod(m, (g.cv.H >> 1) * (g.cv.W >> 1), 4.f * g.cv.r_hw, pn, rem);
-        divmod(rem, g.cv.W >> 1, 2.f * g.cv.r_w, a, b);
-        mr = ((long long)pn * g.cv.H + 2 * a) * g.cv.W + 2 * b;
+    if (m_ok && n_ok) {
+      const long long at = elem_off(p);
+      if (CONV == 0 && !EPI && g.up2) {       // zeros for the three other pixels of the patch
         const u32x4 z = {0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(C + (mr + 1) * g.ldc + n) = z;
-        *reinterpret_cast<u32x4*>(C + (mr + g.cv.W) * g.ldc + n) = z;
-        *reinterpret_cast<u32x4*>(C + (mr + g.cv.W + 1) * g.ldc + n) = z;
+        *reinterpret_cast<u32x4*>(C + at + g.ldc) = z;
+        *reinterpret_cast<u32x4*>(C + at + (long long)g.cv.W * g.ldc) = z;
+        *reinterpret_cast<u32x4*>(C + at + (long long)(g.cv.W + 1) * g.ldc) = z;
       }
-      if (Cin) {
+      if (has_cin) {
         // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
-        u32x4 c = *reinterpret_cast<const u32x4*>(Cin + mr * g.ldc + n);
+        if (!kLean) fetch_cin(p, cin[0], cin_keep[0]);
+        u32x4 c = cin[p % kAhead];
         if (g.cin_mask) {
           // C_in is a gradient that still has to pass a ReLU: the mask its producer would have applied
-          const unsigned keep = g.cin_mask[(c_off + mr * g.ldc + n) >> 3];
+          const unsigned keep = cin_keep[p % kAhead];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             c[e] &= ((keep >> (2 * e)) & 1u ? 0x0000ffffu : 0u) | ((keep >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
@@ -727,66 +809,61 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 2) void gemm_bf16_kernel(GemmArgs
         for (int e = 0; e < 4; ++e) {
           const float lo = __uint_as_float(v[e] << 16) + __uint_as_float(c[e] << 16);
           const float hi = __uint_as_float(v[e] & 0xffff0000u) + __uint_as_float(c[e] & 0xffff0000u);
-          v[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+          v[e] = pack_bf16x2(lo, hi);
         }
       }
-      *reinterpret_cast<u32x4*>(C + mr * g.ldc + n) = v;
+      *reinterpret_cast<u32x4*>(C + at) = v;
       if (bn_grad_stats) {
         // v is the finished gradient (accumulate input included): mask it like the norm's backward will
         const u32x4 xv = bxv[p & 3];
-        const unsigned keep = bkeep[p & 3];
+        if (g.bn_relu == 2) {        // the mask recomputed from the norm's input (one uniform test per pass)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xl = __uint_as_float(xv[e] << 16), xh = __uint_as_float(xv[e] & 0xffff0000u);
-          float gl = __uint_as_float(v[e] << 16), gh = __uint_as_float(v[e] & 0xffff0000u);
-          if (g.bn_relu == 2) {
+          for (int e = 0; e < 4; ++e) {
+            const float xl = __uint_as_float(xv[e] << 16), xh = __uint_as_float(xv[e] & 0xffff0000u);
+            float gl = __uint_as_float(v[e] << 16), gh = __uint_as_float(v[e] & 0xffff0000u);
             gl = fmaf(xl, bsa[2 * e], bsb[2 * e]) > 0.f ? gl : 0.f;
             gh = fmaf(xh, bsa[2 * e + 1], bsb[2 * e + 1]) > 0.f ? gh : 0.f;
-          } else {
-            gl = (keep >> (2 * e)) & 1u ? gl : 0.f;
-            gh = (keep >> (2 * e + 1)) & 1u ? gh : 0.f;
+            cs0[2 * e] += gl; cs1[2 * e] = fmaf(gl, xl - bmu[2 * e], cs1[2 * e]);
+            cs0[2 * e + 1] += gh; cs1[2 * e + 1] = fmaf(gh, xh - bmu[2 * e + 1], cs1[2 * e + 1]);
           }
-          cs0[2 * e] += gl; cs1[2 * e] = fmaf(gl, xl - bmu[2 * e], cs1[2 * e]);
-          cs0[2 * e + 1] += gh; cs1[2 * e + 1] = fmaf(gh, xh - bmu[2 * e + 1], cs1[2 * e + 1]);
+        } else {                     // mask bits (all ones when the norm has no ReLU)
+          const unsigned keep = bkeep[p & 3];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // the pair's bits spread to a dword mask, applied to the packed pair before it is unpacked
+            const unsigned mlo = (unsigned)__builtin_amdgcn_sbfe((int)keep, 2 * e, 1) & 0x0000ffffu;
+            const unsigned mhi = (unsigned)__builtin_amdgcn_sbfe((int)keep, 2 * e + 1, 1) & 0xffff0000u;
+            const unsigned gv = v[e] & (mlo | mhi);
+            const float xl = __uint_as_float(xv[e] << 16), xh = __uint_as_float(xv[e] & 0xffff0000u);
+            const float gl = __uint_as_float(gv << 16), gh = __uint_as_float(gv & 0xffff0000u);
+            cs0[2 * e] += gl; cs1[2 * e] = fmaf(gl, xl - bmu[2 * e], cs1[2 * e]);
+            cs0[2 * e + 1] += gh; cs1[2 * e + 1] = fmaf(gh, xh - bmu[2 * e + 1], cs1[2 * e + 1]);
+          }
         }
       }
     }
     if (p == 3 && kPasses > 4 && bn_grad_stats) fetch_bn(4);
   }
-  if (g.col_stats) {
-    // combine the 8 lanes that hold the same chunk (lane ^ 8, 16, 32): fixed order, no atomics
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      cs0[e] = sum_lanes_8_16_32(cs0[e]);
-      cs1[e] = sum_lanes_8_16_32(cs1[e]);
-    }
+  if (stats0 || bn_grad_stats) {
+    // combine the 8 lanes that hold the same chunk (lane ^ 8, 16, 32): fixed order, no atomics. Afterwards a lane
+    // holds 4 of the chunk's 16 totals: statistic (lane >> 4) & 1, elements 4 h .. 4 h + 3 with h = lane >> 5
+    float t[4];
+    sum16_lanes_8_16_32(cs0, cs1, t);
+    const int st = (lane >> 4) & 1, hh = lane >> 5;
+    const bool owner = !(lane & 8);                          // lane ^ 8 holds the same four values
     // ... then the waves of the block that cover the same columns (those stacked along m), through LDS and in
     // wave order: ONE partial row per 128-row tile, so the buffer and the fold kernel that sums it stay small
     float* red = reinterpret_cast<float*>(smem);            // [4 waves][2][64 columns]
+    const int at = st * 64 + chunk * 8 + hh * 4;
     __syncthreads();                                         // every wave is done with its staging area
-    if (lane < 8) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[(wid * 2 + 0) * 64 + lane * 8 + e] = cs0[e];
-        red[(wid * 2 + 1) * 64 + lane * 8 + e] = cs1[e];
-      }
-    }
+    if (owner && wm != 0) *reinterpret_cast<f32x4*>(red + wid * 128 + at) = f32x4{t[0], t[1], t[2], t[3]};
     __syncthreads();
-    const int n = wn0 + lane * 8;
-    if (wm == 0 && lane < 8 && n < g.N) {
+    if (owner && wm == 0 && n_ok) {
       constexpr int kStep = V ? 1 : 2, kCount = V ? 4 : 2;   // wave ids of the waves below this one
+      f32x4 sum = {t[0], t[1], t[2], t[3]};
 #pragma unroll
-      for (int q = 1; q < kCount; ++q)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          cs0[e] += red[((wid + q * kStep) * 2 + 0) * 64 + lane * 8 + e];
-          cs1[e] += red[((wid + q * kStep) * 2 + 1) * 64 + lane * 8 + e];
-        }
-      float* dst = g.col_stats + ((long long)(m0 / BM) * 2) * g.N + n;
-      *reinterpret_cast<f32x4*>(dst) = f32x4{cs0[0], cs0[1], cs0[2], cs0[3]};
-      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs0[4], cs0[5], cs0[6], cs0[7]};
-      *reinterpret_cast<f32x4*>(dst + g.N) = f32x4{cs1[0], cs1[1], cs1[2], cs1[3]};
-      *reinterpret_cast<f32x4*>(dst + g.N + 4) = f32x4{cs1[4], cs1[5], cs1[6], cs1[7]};
+      for (int q = 1; q < kCount; ++q) sum += *reinterpret_cast<const f32x4*>(red + (wid + q * kStep) * 128 + at);
+      *reinterpret_cast<f32x4*>(g.col_stats + ((long long)(m0 / BM) * 2 + st) * g.N + n + hh * 4) = sum;
     }
   }
 }
@@ -891,6 +968,9 @@ DTF_API int dtf_splitk_reduce(const float* W, void* C, const void* bias, int bia
   return (int)hipGetLastError();
 }
 
+static int g_lean = 1;                   // lean store phase where it applies (measurement hook: 0 = never)
+DTF_API void dtf_gemm_set_lean(int on) { g_lean = on != 0; }
+
 static int g_stages = 0;                 // 0 = automatic
 constexpr int kSingleStageTiles = 1 << 20;   // in effect always: one buffer also measured faster on the long weight-gradient loops
 
@@ -915,6 +995,9 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   const int variant = ex && ex->tile == 1 ? 1 : 0;
   const int bn_cols = variant ? 64 : BN;
   g.tiles_n = (N + bn_cols - 1) / bn_cols;
+  g.tn_shift = -1;
+  for (int sft = 0; sft < 16; ++sft)
+    if (g.tiles_n == (1 << sft)) g.tn_shift = sft;
   int batch = 1, conv = 0;
   g.nb2 = 1; g.sA1 = g.sA2 = g.sB1 = g.sB2 = g.sC1 = g.sC2 = 0;
   ConvGeom& c = g.cv;
@@ -1012,6 +1095,19 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   const size_t b_tile = (layout == 0 && variant ? 64 : 128) * BK * 2;
   const size_t stage_bytes = kTileBytes + b_tile;
   const size_t lds = (stages == 2 ? 2 : 1) * stage_bytes;
+  // the lean store-phase variant that matches the request exactly (0 = none does: the general kernel)
+  int epi = 0;
+  if (g_lean && splits == 1 && !bias && act == 0 && !g.drop_thresh && !out_fp32 && !g.up2 && stages == 1 && conv == 0 &&
+      layout != 2 && !g.tf_scale && batch == 1) {
+    epi = 1 | (g.col_stats && g.stats_mode == 0 ? 2 : 0) | (g.Cin ? 4 : 0) | (g.col_stats && g.stats_mode == 1 ? 8 : 0);
+    const bool have = layout == 0 ? (epi == 1 || epi == 3) : (epi == 1 || epi == 5 || epi == 9 || epi == 13);
+    if (!have) epi = 0;
+  }
+#define GEMM_LEAN(BT, E)                                                                                       \
+  do {                                                                                                         \
+    if (variant) hipLaunchKernelGGL((gemm_bf16_kernel<0, BT, 0, 1, 1, 0, E>), grid, dim3(kThreads), lds, stream, g); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<0, BT, 0, 1, 0, 0, E>), grid, dim3(kThreads), lds, stream, g);     \
+  } while (0)
 #define GEMM_LAUNCH(AT, BT, CV)                                                                              \
   do {                                                                                                       \
     if (variant) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 1, 1>), grid, dim3(kThreads), lds, stream, g); \
@@ -1029,6 +1125,16 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
     else if (layout == 2 && conv == 0) GEMM_LAUNCH_TF(1, 1, 0, 2);
     else if (layout == 2 && conv == 3) GEMM_LAUNCH_TF(1, 1, 3, 2);
     else GEMM_LAUNCH_TF(1, 1, 4, 1);
+  } else if (epi) {
+    switch (layout * 16 + epi) {
+      case 1: GEMM_LEAN(0, 1); break;
+      case 3: GEMM_LEAN(0, 3); break;
+      case 16 + 1: GEMM_LEAN(1, 1); break;
+      case 16 + 5: GEMM_LEAN(1, 5); break;
+      case 16 + 9: GEMM_LEAN(1, 9); break;
+      case 16 + 13: GEMM_LEAN(1, 13); break;
+      default: return -1;
+    }
   } else if (conv == 0) {
     switch (layout) {
       case 0: GEMM_LAUNCH(0, 0, 0); break;
@@ -1042,6 +1148,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   else if (conv == 4 && layout == 2) GEMM_LAUNCH(1, 1, 4);
   else return -1;
 #undef GEMM_LAUNCH
+#undef GEMM_LEAN
 #undef GEMM_LAUNCH_TF
   if (splits > 1) {
     const long long n4 = (long long)M * (N / 4);

@@ -385,8 +385,8 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
                 const f32x4 lo = gelu_pair256(f32x2_256{v[0], v[1]}), hi = gelu_pair256(f32x2_256{v[2], v[3]});
                 v = f32x4{lo[0], lo[1], hi[0], hi[1]};
                 const f32x4 d = {lo[2], lo[3], hi[2], hi[3]};
-                side[i * 2 + j][0] = (unsigned)f32_to_bf16(d[0]) | ((unsigned)f32_to_bf16(d[1]) << 16);
-                side[i * 2 + j][1] = (unsigned)f32_to_bf16(d[2]) | ((unsigned)f32_to_bf16(d[3]) << 16);
+                side[i * 2 + j][0] = pack_bf16x2(d[0], d[1]);
+                side[i * 2 + j][1] = pack_bf16x2(d[2], d[3]);
               } else if (ACT == 2) {
                 const f32x4 lo = gelu_pair256(f32x2_256{v[0], v[1]}), hi = gelu_pair256(f32x2_256{v[2], v[3]});
                 v = f32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -395,8 +395,8 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
               }
               u32x2 o;
-              o[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-              o[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+              o[0] = pack_bf16x2(v[0], v[1]);
+              o[1] = pack_bf16x2(v[2], v[3]);
               *reinterpret_cast<u32x2*>(blk + (i * 16 + fr_e) * 64 + j * 32 + fq_e * 8) = o;
             }
           // the staging block is private to the wave: LDS operations of one wave execute in order
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
                     const float c0 = __uint_as_float(ci[e] << 16), c1 = __uint_as_float(ci[e] & 0xffff0000u);
                     const float lo = CIN == 1 ? a0 + c0 : a0 * c0;
                     const float hi = CIN == 1 ? a1 + c1 : a1 * c1;
-                    val[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                    val[e] = pack_bf16x2(lo, hi);
                   }
                 }
                 *reinterpret_cast<u32x4*>(dst + (long long)m * g.ldc + n) = val;

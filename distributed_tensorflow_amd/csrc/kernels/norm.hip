@@ -28,10 +28,7 @@ __device__ __forceinline__ void ld8bf(const unsigned short* p, float (&o)[8]) {
   for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(a[i]);
 }
 __device__ __forceinline__ void st8bf(unsigned short* p, const float (&o)[8]) {
-  u16x8 a;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = f32_to_bf16(o[i]);
-  *reinterpret_cast<u16x8*>(p) = a;
+  store8_bf16(p, o);
 }
 __device__ __forceinline__ void ld8f(const float* p, float (&o)[8]) {
   f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
@@ -813,7 +810,7 @@ __global__ __launch_bounds__(kBlock, 4) void bn_pool322_apply_bwd_kernel(const u
             const float e1 = fmaf(v1, sa[k + 1], sb[k + 1]) > 0.f ? d1[a][b] : 0.f;
             const float r0 = fmaf(a8[k], e0, fmaf(kk[k], v0, z[k]));
             const float r1 = fmaf(a8[k + 1], e1, fmaf(kk[k + 1], v1, z[k + 1]));
-            o[a][b][k >> 1] = (unsigned)f32_to_bf16(r0) | ((unsigned)f32_to_bf16(r1) << 16);
+            o[a][b][k >> 1] = pack_bf16x2(r0, r1);
           }
       }
 #pragma unroll

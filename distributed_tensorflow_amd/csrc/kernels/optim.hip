@@ -123,10 +123,7 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, con
     }
     p4[i] = pp; m4[i] = mm; v4[i] = vv;
     if (SHADOW) {
-      u16x4 s;
-      s[0] = f32_to_bf16(pp[0]); s[1] = f32_to_bf16(pp[1]);
-      s[2] = f32_to_bf16(pp[2]); s[3] = f32_to_bf16(pp[3]);
-      reinterpret_cast<u16x4*>(shadow)[i] = s;
+      store4_bf16(shadow + 4 * i, pp[0], pp[1], pp[2], pp[3]);
     }
   }
   // scalar tail (n % 4 elements), handled by the first threads of block 0
@@ -175,10 +172,7 @@ __global__ __launch_bounds__(kBlock) void sgdm_kernel(float* __restrict__ p, con
     }
     p4[i] = pp; v4[i] = vv;
     if (SHADOW) {
-      u16x4 s;
-      s[0] = f32_to_bf16(pp[0]); s[1] = f32_to_bf16(pp[1]);
-      s[2] = f32_to_bf16(pp[2]); s[3] = f32_to_bf16(pp[3]);
-      reinterpret_cast<u16x4*>(shadow)[i] = s;
+      store4_bf16(shadow + 4 * i, pp[0], pp[1], pp[2], pp[3]);
     }
   }
   const long long tail0 = n4 << 2;

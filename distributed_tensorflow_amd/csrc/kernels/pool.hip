@@ -51,11 +51,10 @@ __global__ __launch_bounds__(kBlock) void maxpool_fwd_kernel(const unsigned shor
         }
       }
     }
-    u16x8 o;
     u8x8 a;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { o[k] = f32_to_bf16(best[k]); a[k] = arg[k]; }
-    *reinterpret_cast<u16x8*>(y + i * 8) = o;
+    for (int k = 0; k < 8; ++k) a[k] = arg[k];
+    store8_bf16(y + i * 8, best);
     *reinterpret_cast<u8x8*>(idx + i * 8) = a;
   }
 }
@@ -92,10 +91,7 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_kernel(const unsigned shor
         for (int k = 0; k < 8; ++k) acc[k] += a[k] == tap ? bf16_to_f32(v[k]) : 0.f;
       }
     }
-    u16x8 r;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = f32_to_bf16(acc[k]);
-    *reinterpret_cast<u16x8*>(gx + i * 8) = r;
+    store8_bf16(gx + i * 8, acc);
   }
 }
 
