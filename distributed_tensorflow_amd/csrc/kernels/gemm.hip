@@ -123,6 +123,7 @@ struct GemmArgs {
   const float* tf_shift;
   int tf_relu;
   int tn_shift;      // log2(tiles_n) when tiles_n is a power of two, else -1
+  int xcd_splits;    // 1: flat grid, the tiles of a split share an XCD (see the kernel's tile map)
   ConvGeom cv;
 };
 
@@ -441,8 +442,20 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 3) void gemm_bf16_kernel(GemmArgs
   const int ntaps = CONV == 3 ? (g.cv.fold ? g.cv.KH : g.cv.KH * g.cv.KW) : 1;
   const int nwg = g.tiles_m * g.tiles_n * ntaps;
   const int orig = blockIdx.x;
-  const int xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
-  const int vt = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+  int vt, split = blockIdx.y;
+  if (A_T == 1 && g.xcd_splits) {
+    // Weight gradient with the contraction split over the pixels: the blocks of ONE split (all tiles, all filter
+    // taps) read the same slab of both operands, so they are placed on one XCD, next to each other in dispatch
+    // order, and the slab crosses the fabric once instead of once per block. The grid is flat: block L runs on
+    // XCD L % 8; XCD x works through splits x, x + 8, ...
+    const int i = orig >> 3, sl = i / nwg;
+    vt = i - sl * nwg;
+    split = sl * 8 + (orig & 7);
+    if (split >= g.splits) return;           // the grid is padded to a multiple of 8 splits
+  } else {
+    const int xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
+    vt = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+  }
   const int tile = vt / ntaps;
   const int tap = vt - tile * ntaps;
   int tm = g.tn_shift >= 0 ? tile >> g.tn_shift : tile / g.tiles_n;   // tiles_n is a power of two in most launches
@@ -452,7 +465,6 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 3) void gemm_bf16_kernel(GemmArgs
   // row tiles of the four classes out round-robin so that every XCD gets the same mix.
   if (CONV == 2 && g.cv.S == 2 && (g.tiles_m & 3) == 0) tm = (tm & 3) * (g.tiles_m >> 2) + (tm >> 2);
   const int m0 = tm * BM, n0 = tn * BN_;
-  const int split = blockIdx.y;
   const int plane = CONV == 3 ? tap : (int)blockIdx.z;
   const int planes = CONV == 3 ? ntaps : (int)gridDim.z;
   // lean variants are launched for a single plane only
@@ -704,145 +716,242 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 3) void gemm_bf16_kernel(GemmArgs
       bsb[e] = in && g.bn_relu == 2 ? g.bn_shift[n + e] : 0.f;
     }
   }
-  // The lane's chunk of pass p: row wm0 + row0 + 8 p of the output, columns n .. n + 7.
-  constexpr int kPasses = WTM / 8;           // 64 lanes x 16 bytes = 8 rows of the sub-tile per pass
-  const int row0 = lane >> 3, chunk = lane & 7;
+  // chunk of the lane in the tile's column statistics (both store-phase forms)
+  const int chunk = lane & 7;
   const int n = wn0 + chunk * 8;
   const bool n_ok = n < g.N;
-  const bool full_m = wm0 + WTM <= g.M;      // uniform: no row of the wave's sub-tile is past the edge
-  const bool remap = (CONV == 2 && g.cv.S == 2) || (CONV == 0 && !EPI && g.up2);
-  auto row_ok = [&](int p) { return full_m || wm0 + row0 + 8 * p < g.M; };
-  // lean variants step a precomputed 64-bit offset from pass to pass; the general kernel, short of registers,
-  // multiplies afresh
-  const long long off0 = kLean ? (long long)(wm0 + row0) * g.ldc + n : 0, step = kLean ? 8LL * g.ldc : 0;
-  auto linear_off = [&](int p) { return kLean ? off0 + p * step : (long long)(wm0 + row0 + 8 * p) * g.ldc + n; };
-  auto elem_off = [&](int p) -> long long {  // elements from C (and C_in) to that chunk
-    if (!remap) return linear_off(p);
-    const int m = wm0 + row0 + 8 * p;
-    long long mr;
-    if (CONV == 2) {                         // class-ordered GEMM row -> pixel row in memory
-      int pn, ph, pw;
-      dgrad_pixel(g.cv, m, pn, ph, pw);
-      mr = ((long long)pn * g.cv.H + ph) * g.cv.W + pw;
-    } else {                                 // up2: the even pixel of the 2x2 patch the row stands for
-      int pn, rem, a, b;
-      divmod(m, (g.cv.H >> 1) * (g.cv.W >> 1), 4.f * g.cv.r_hw, pn, rem);
-      divmod(rem, g.cv.W >> 1, 2.f * g.cv.r_w, a, b);
-      mr = ((long long)pn * g.cv.H + 2 * a) * g.cv.W + 2 * b;
-    }
-    return mr * g.ldc + n;
-  };
-  // Lean variants request everything the passes read before the first of them runs, so that a tile pays each
-  // latency once: the accumulate input (global), the norm's input and mask bytes of the first four passes (global;
-  // all eight would cost the kernel its third resident block), then the staged rows (LDS). The accumulators are
-  // dead by now and their registers take the data. The general kernel, whose run-time feature tests keep more
-  // alive, fetches pass by pass (it would lose a resident block to the extra registers).
-  constexpr int kAhead = kLean ? kPasses : 1;
-  u32x4 cin[kAhead];
-  unsigned cin_keep[kAhead];
-  auto fetch_cin = [&](int p, u32x4& c, unsigned& keep) {
-    c = u32x4{0u, 0u, 0u, 0u};
-    keep = 0xffu;
-    if (row_ok(p) && n_ok) {
-      const long long at = elem_off(p);
-      c = *reinterpret_cast<const u32x4*>(Cin + at);
-      if (g.cin_mask) keep = g.cin_mask[(c_off + at) >> 3];
-    }
-  };
-  if (kLean && has_cin) {
-#pragma unroll
-    for (int p = 0; p < kAhead; ++p) fetch_cin(p, cin[p], cin_keep[p]);
-  }
-  u32x4 bxv[4];
-  unsigned bkeep[4];
-  auto fetch_bn = [&](int p0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      bxv[q] = u32x4{0u, 0u, 0u, 0u};
-      bkeep[q] = 0xffu;
-      if (row_ok(p0 + q) && n_ok) {
-        const long long at = c_off + linear_off(p0 + q);
-        bxv[q] = *reinterpret_cast<const u32x4*>(g.bn_x + at);
-        if (g.bn_relu == 3) bkeep[q] = g.bn_mask[at >> 3];
+  if constexpr (kLean) {
+    // The lane's chunk of pass p: row wm0 + row0 + 8 p of the output, columns n .. n + 7.
+    constexpr int kPasses = WTM / 8;           // 64 lanes x 16 bytes = 8 rows of the sub-tile per pass
+    const int row0 = lane >> 3;
+    const bool full_m = wm0 + WTM <= g.M;      // uniform: no row of the wave's sub-tile is past the edge
+    const bool remap = (CONV == 2 && g.cv.S == 2) || (CONV == 0 && !EPI && g.up2);
+    auto row_ok = [&](int p) { return full_m || wm0 + row0 + 8 * p < g.M; };
+    // lean variants step a precomputed 64-bit offset from pass to pass; the general kernel, short of registers,
+    // multiplies afresh
+    const long long off0 = kLean ? (long long)(wm0 + row0) * g.ldc + n : 0, step = kLean ? 8LL * g.ldc : 0;
+    auto linear_off = [&](int p) { return kLean ? off0 + p * step : (long long)(wm0 + row0 + 8 * p) * g.ldc + n; };
+    auto elem_off = [&](int p) -> long long {  // elements from C (and C_in) to that chunk
+      if (!remap) return linear_off(p);
+      const int m = wm0 + row0 + 8 * p;
+      long long mr;
+      if (CONV == 2) {                         // class-ordered GEMM row -> pixel row in memory
+        int pn, ph, pw;
+        dgrad_pixel(g.cv, m, pn, ph, pw);
+        mr = ((long long)pn * g.cv.H + ph) * g.cv.W + pw;
+      } else {                                 // up2: the even pixel of the 2x2 patch the row stands for
+        int pn, rem, a, b;
+        divmod(m, (g.cv.H >> 1) * (g.cv.W >> 1), 4.f * g.cv.r_hw, pn, rem);
+        divmod(rem, g.cv.W >> 1, 2.f * g.cv.r_w, a, b);
+        mr = ((long long)pn * g.cv.H + 2 * a) * g.cv.W + 2 * b;
       }
-    }
-  };
-  if (bn_grad_stats) fetch_bn(0);
-  u32x4 staged[kAhead];
-  if (kLean) {
-#pragma unroll
-    for (int p = 0; p < kAhead; ++p)
-      staged[p] = *reinterpret_cast<const u32x4*>(stage + swz_off(row0 + 8 * p, chunk));
-  }
-#pragma unroll
-  for (int p = 0; p < kPasses; ++p) {
-    u32x4 v = kLean ? staged[p % kAhead] : *reinterpret_cast<const u32x4*>(stage + swz_off(row0 + 8 * p, chunk));
-    const bool m_ok = row_ok(p);
-    if (stats0 && m_ok) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
-        cs0[2 * e] += lo; cs1[2 * e] = fmaf(lo, lo, cs1[2 * e]);
-        cs0[2 * e + 1] += hi; cs1[2 * e + 1] = fmaf(hi, hi, cs1[2 * e + 1]);
+      return mr * g.ldc + n;
+    };
+    // Lean variants request everything the passes read before the first of them runs, so that a tile pays each
+    // latency once: the accumulate input (global), the norm's input and mask bytes of the first four passes (global;
+    // all eight would cost the kernel its third resident block), then the staged rows (LDS). The accumulators are
+    // dead by now and their registers take the data. The general kernel, whose run-time feature tests keep more
+    // alive, fetches pass by pass (it would lose a resident block to the extra registers).
+    constexpr int kAhead = kLean ? kPasses : 1;
+    u32x4 cin[kAhead];
+    unsigned cin_keep[kAhead];
+    auto fetch_cin = [&](int p, u32x4& c, unsigned& keep) {
+      c = u32x4{0u, 0u, 0u, 0u};
+      keep = 0xffu;
+      if (row_ok(p) && n_ok) {
+        const long long at = elem_off(p);
+        c = *reinterpret_cast<const u32x4*>(Cin + at);
+        if (g.cin_mask) keep = g.cin_mask[(c_off + at) >> 3];
       }
+    };
+    if (kLean && has_cin) {
+  #pragma unroll
+      for (int p = 0; p < kAhead; ++p) fetch_cin(p, cin[p], cin_keep[p]);
     }
-    if (m_ok && n_ok) {
-      const long long at = elem_off(p);
-      if (CONV == 0 && !EPI && g.up2) {       // zeros for the three other pixels of the patch
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(C + at + g.ldc) = z;
-        *reinterpret_cast<u32x4*>(C + at + (long long)g.cv.W * g.ldc) = z;
-        *reinterpret_cast<u32x4*>(C + at + (long long)(g.cv.W + 1) * g.ldc) = z;
-      }
-      if (has_cin) {
-        // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
-        if (!kLean) fetch_cin(p, cin[0], cin_keep[0]);
-        u32x4 c = cin[p % kAhead];
-        if (g.cin_mask) {
-          // C_in is a gradient that still has to pass a ReLU: the mask its producer would have applied
-          const unsigned keep = cin_keep[p % kAhead];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            c[e] &= ((keep >> (2 * e)) & 1u ? 0x0000ffffu : 0u) | ((keep >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+    u32x4 bxv[4];
+    unsigned bkeep[4];
+    auto fetch_bn = [&](int p0) {
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bxv[q] = u32x4{0u, 0u, 0u, 0u};
+        bkeep[q] = 0xffu;
+        if (row_ok(p0 + q) && n_ok) {
+          const long long at = c_off + linear_off(p0 + q);
+          bxv[q] = *reinterpret_cast<const u32x4*>(g.bn_x + at);
+          if (g.bn_relu == 3) bkeep[q] = g.bn_mask[at >> 3];
         }
-#pragma unroll
+      }
+    };
+    if (bn_grad_stats) fetch_bn(0);
+    u32x4 staged[kAhead];
+    if (kLean) {
+  #pragma unroll
+      for (int p = 0; p < kAhead; ++p)
+        staged[p] = *reinterpret_cast<const u32x4*>(stage + swz_off(row0 + 8 * p, chunk));
+    }
+  #pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+      u32x4 v = kLean ? staged[p % kAhead] : *reinterpret_cast<const u32x4*>(stage + swz_off(row0 + 8 * p, chunk));
+      const bool m_ok = row_ok(p);
+      if (stats0 && m_ok) {
+  #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float lo = __uint_as_float(v[e] << 16) + __uint_as_float(c[e] << 16);
-          const float hi = __uint_as_float(v[e] & 0xffff0000u) + __uint_as_float(c[e] & 0xffff0000u);
-          v[e] = pack_bf16x2(lo, hi);
+          const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+          cs0[2 * e] += lo; cs1[2 * e] = fmaf(lo, lo, cs1[2 * e]);
+          cs0[2 * e + 1] += hi; cs1[2 * e + 1] = fmaf(hi, hi, cs1[2 * e + 1]);
         }
       }
-      *reinterpret_cast<u32x4*>(C + at) = v;
-      if (bn_grad_stats) {
-        // v is the finished gradient (accumulate input included): mask it like the norm's backward will
-        const u32x4 xv = bxv[p & 3];
-        if (g.bn_relu == 2) {        // the mask recomputed from the norm's input (one uniform test per pass)
-#pragma unroll
+      if (m_ok && n_ok) {
+        const long long at = elem_off(p);
+        if (CONV == 0 && !EPI && g.up2) {       // zeros for the three other pixels of the patch
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(C + at + g.ldc) = z;
+          *reinterpret_cast<u32x4*>(C + at + (long long)g.cv.W * g.ldc) = z;
+          *reinterpret_cast<u32x4*>(C + at + (long long)(g.cv.W + 1) * g.ldc) = z;
+        }
+        if (has_cin) {
+          // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
+          if (!kLean) fetch_cin(p, cin[0], cin_keep[0]);
+          u32x4 c = cin[p % kAhead];
+          if (g.cin_mask) {
+            // C_in is a gradient that still has to pass a ReLU: the mask its producer would have applied
+            const unsigned keep = cin_keep[p % kAhead];
+  #pragma unroll
+            for (int e = 0; e < 4; ++e)
+              c[e] &= ((keep >> (2 * e)) & 1u ? 0x0000ffffu : 0u) | ((keep >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+          }
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(v[e] << 16) + __uint_as_float(c[e] << 16);
+            const float hi = __uint_as_float(v[e] & 0xffff0000u) + __uint_as_float(c[e] & 0xffff0000u);
+            v[e] = pack_bf16x2(lo, hi);
+          }
+        }
+        *reinterpret_cast<u32x4*>(C + at) = v;
+        if (bn_grad_stats) {
+          // v is the finished gradient (accumulate input included): mask it like the norm's backward will
+          const u32x4 xv = bxv[p & 3];
+          if (g.bn_relu == 2) {        // the mask recomputed from the norm's input (one uniform test per pass)
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xl = __uint_as_float(xv[e] << 16), xh = __uint_as_float(xv[e] & 0xffff0000u);
+              float gl = __uint_as_float(v[e] << 16), gh = __uint_as_float(v[e] & 0xffff0000u);
+              gl = fmaf(xl, bsa[2 * e], bsb[2 * e]) > 0.f ? gl : 0.f;
+              gh = fmaf(xh, bsa[2 * e + 1], bsb[2 * e + 1]) > 0.f ? gh : 0.f;
+              cs0[2 * e] += gl; cs1[2 * e] = fmaf(gl, xl - bmu[2 * e], cs1[2 * e]);
+              cs0[2 * e + 1] += gh; cs1[2 * e + 1] = fmaf(gh, xh - bmu[2 * e + 1], cs1[2 * e + 1]);
+            }
+          } else {                     // mask bits (all ones when the norm has no ReLU)
+            const unsigned keep = bkeep[p & 3];
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // the pair's bits spread to a dword mask, applied to the packed pair before it is unpacked
+              const unsigned mlo = (unsigned)__builtin_amdgcn_sbfe((int)keep, 2 * e, 1) & 0x0000ffffu;
+              const unsigned mhi = (unsigned)__builtin_amdgcn_sbfe((int)keep, 2 * e + 1, 1) & 0xffff0000u;
+              const unsigned gv = v[e] & (mlo | mhi);
+              const float xl = __uint_as_float(xv[e] << 16), xh = __uint_as_float(xv[e] & 0xffff0000u);
+              const float gl = __uint_as_float(gv << 16), gh = __uint_as_float(gv & 0xffff0000u);
+              cs0[2 * e] += gl; cs1[2 * e] = fmaf(gl, xl - bmu[2 * e], cs1[2 * e]);
+              cs0[2 * e + 1] += gh; cs1[2 * e + 1] = fmaf(gh, xh - bmu[2 * e + 1], cs1[2 * e + 1]);
+            }
+          }
+        }
+      }
+      if (p == 3 && kPasses > 4 && bn_grad_stats) fetch_bn(4);
+    }
+  } else {
+    // The general store phase goes pass by pass: read the staged row, fetch what the pass needs, store. Its
+    // run-time feature tests keep too much alive for the look-ahead of the lean form.
+    // ... and the norm's input (and mask bytes), fetched four passes at a time so that their latency is paid twice
+    // per tile rather than per pass (all eight at once would cost the kernel its third resident block)
+    u32x4 bxv[4];
+    unsigned bkeep[4];
+    auto fetch_bn = [&](int p0) {
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int id = lane + 64 * (p0 + q);
+        const int m = wm0 + (id >> 3), n = wn0 + (id & 7) * 8;
+        bxv[q] = u32x4{0u, 0u, 0u, 0u};
+        bkeep[q] = 0xffu;
+        if (m < g.M && n < g.N) {
+          const long long at = c_off + (long long)m * g.ldc + n;
+          bxv[q] = *reinterpret_cast<const u32x4*>(g.bn_x + at);
+          if (g.bn_relu == 3) bkeep[q] = g.bn_mask[at >> 3];
+        }
+      }
+    };
+    if (bn_grad_stats) fetch_bn(0);
+    constexpr int kPasses = WTM / 8;           // 64 lanes x 16 bytes = 8 rows of the sub-tile per pass
+  #pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+      const int id = lane + 64 * p;
+      const int row = id >> 3, chunk = id & 7;
+      const int m = wm0 + row, n = wn0 + chunk * 8;
+      u32x4 v = *reinterpret_cast<const u32x4*>(stage + swz_off(row, chunk));
+      if (stats0 && m < g.M) {
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+          cs0[2 * e] += lo; cs1[2 * e] = fmaf(lo, lo, cs1[2 * e]);
+          cs0[2 * e + 1] += hi; cs1[2 * e + 1] = fmaf(hi, hi, cs1[2 * e + 1]);
+        }
+      }
+      if (m < g.M && n < g.N) {
+        long long mr = m;
+        if (CONV == 2 && g.cv.S == 2) {       // class-ordered GEMM row -> pixel row in memory
+          int pn, ph, pw;
+          dgrad_pixel(g.cv, m, pn, ph, pw);
+          mr = ((long long)pn * g.cv.H + ph) * g.cv.W + pw;
+        } else if (CONV == 0 && g.up2) {
+          int pn, rem, a, b;
+          divmod(m, (g.cv.H >> 1) * (g.cv.W >> 1), 4.f * g.cv.r_hw, pn, rem);
+          divmod(rem, g.cv.W >> 1, 2.f * g.cv.r_w, a, b);
+          mr = ((long long)pn * g.cv.H + 2 * a) * g.cv.W + 2 * b;
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(C + (mr + 1) * g.ldc + n) = z;
+          *reinterpret_cast<u32x4*>(C + (mr + g.cv.W) * g.ldc + n) = z;
+          *reinterpret_cast<u32x4*>(C + (mr + g.cv.W + 1) * g.ldc + n) = z;
+        }
+        if (has_cin) {
+          // out = bf16(bf16(acc) + C_in): the rounding of an unfused GEMM followed by an add kernel
+          u32x4 c = *reinterpret_cast<const u32x4*>(Cin + mr * g.ldc + n);
+          if (g.cin_mask) {
+            // C_in is a gradient that still has to pass a ReLU: the mask its producer would have applied
+            const unsigned keep = g.cin_mask[(c_off + mr * g.ldc + n) >> 3];
+  #pragma unroll
+            for (int e = 0; e < 4; ++e)
+              c[e] &= ((keep >> (2 * e)) & 1u ? 0x0000ffffu : 0u) | ((keep >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+          }
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(v[e] << 16) + __uint_as_float(c[e] << 16);
+            const float hi = __uint_as_float(v[e] & 0xffff0000u) + __uint_as_float(c[e] & 0xffff0000u);
+            v[e] = pack_bf16x2(lo, hi);
+          }
+        }
+        *reinterpret_cast<u32x4*>(C + mr * g.ldc + n) = v;
+        if (bn_grad_stats) {
+          // v is the finished gradient (accumulate input included): mask it like the norm's backward will
+          const u32x4 xv = bxv[p & 3];
+          const unsigned keep = bkeep[p & 3];
+  #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float xl = __uint_as_float(xv[e] << 16), xh = __uint_as_float(xv[e] & 0xffff0000u);
             float gl = __uint_as_float(v[e] << 16), gh = __uint_as_float(v[e] & 0xffff0000u);
-            gl = fmaf(xl, bsa[2 * e], bsb[2 * e]) > 0.f ? gl : 0.f;
-            gh = fmaf(xh, bsa[2 * e + 1], bsb[2 * e + 1]) > 0.f ? gh : 0.f;
-            cs0[2 * e] += gl; cs1[2 * e] = fmaf(gl, xl - bmu[2 * e], cs1[2 * e]);
-            cs0[2 * e + 1] += gh; cs1[2 * e + 1] = fmaf(gh, xh - bmu[2 * e + 1], cs1[2 * e + 1]);
-          }
-        } else {                     // mask bits (all ones when the norm has no ReLU)
-          const unsigned keep = bkeep[p & 3];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // the pair's bits spread to a dword mask, applied to the packed pair before it is unpacked
-            const unsigned mlo = (unsigned)__builtin_amdgcn_sbfe((int)keep, 2 * e, 1) & 0x0000ffffu;
-            const unsigned mhi = (unsigned)__builtin_amdgcn_sbfe((int)keep, 2 * e + 1, 1) & 0xffff0000u;
-            const unsigned gv = v[e] & (mlo | mhi);
-            const float xl = __uint_as_float(xv[e] << 16), xh = __uint_as_float(xv[e] & 0xffff0000u);
-            const float gl = __uint_as_float(gv << 16), gh = __uint_as_float(gv & 0xffff0000u);
+            if (g.bn_relu == 2) {
+              gl = fmaf(xl, bsa[2 * e], bsb[2 * e]) > 0.f ? gl : 0.f;
+              gh = fmaf(xh, bsa[2 * e + 1], bsb[2 * e + 1]) > 0.f ? gh : 0.f;
+            } else {
+              gl = (keep >> (2 * e)) & 1u ? gl : 0.f;
+              gh = (keep >> (2 * e + 1)) & 1u ? gh : 0.f;
+            }
             cs0[2 * e] += gl; cs1[2 * e] = fmaf(gl, xl - bmu[2 * e], cs1[2 * e]);
             cs0[2 * e + 1] += gh; cs1[2 * e + 1] = fmaf(gh, xh - bmu[2 * e + 1], cs1[2 * e + 1]);
           }
         }
       }
+      if (p == 3 && kPasses > 4 && bn_grad_stats) fetch_bn(4);
     }
-    if (p == 3 && kPasses > 4 && bn_grad_stats) fetch_bn(4);
   }
   if (stats0 || bn_grad_stats) {
     // combine the 8 lanes that hold the same chunk (lane ^ 8, 16, 32): fixed order, no atomics. Afterwards a lane
@@ -968,6 +1077,9 @@ DTF_API int dtf_splitk_reduce(const float* W, void* C, const void* bias, int bia
   return (int)hipGetLastError();
 }
 
+static int g_xcd_splits = 1;             // split-K weight gradients: tiles of a split on one XCD (measurement hook)
+DTF_API void dtf_gemm_set_xcd_splits(int on) { g_xcd_splits = on != 0; }
+
 static int g_lean = 1;                   // lean store phase where it applies (measurement hook: 0 = never)
 DTF_API void dtf_gemm_set_lean(int on) { g_lean = on != 0; }
 
@@ -1085,7 +1197,12 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   g.C = splits > 1 ? workspace : C;
   if (splits > 1 && !workspace) return -3;
   // the taps of a weight-gradient launch are folded into grid.x (see the kernel's tile map)
-  const dim3 grid(g.tiles_m * g.tiles_n * (conv == 3 ? batch : 1), splits, conv == 3 ? 1 : batch);
+  dim3 grid(g.tiles_m * g.tiles_n * (conv == 3 ? batch : 1), splits, conv == 3 ? 1 : batch);
+  g.xcd_splits = 0;
+  if (g_xcd_splits && layout == 2 && (conv == 0 || conv == 3 || conv == 4) && splits > 1 && grid.x > 1) {
+    g.xcd_splits = 1;
+    grid = dim3(grid.x * ((splits + 7) / 8 * 8), 1, grid.z);
+  }
   // LDS stages: two buffers pay when a block runs a long k-loop at ~2 blocks per CU; short loops
   // (k-tiles per block <= kSingleStageTiles) are latency- and bandwidth-bound and run better with one
   // buffer and twice the resident blocks. g_stages overrides (1 or 2) for A/B measurements.

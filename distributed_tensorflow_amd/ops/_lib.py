@@ -52,6 +52,8 @@ def kernels() -> ctypes.CDLL:
         cap = os.environ.get("DTF_STREAM_BLOCKS")       # A/B switch: grid cap of the streaming kernels
         if cap:
             _kernels.dtf_set_stream_blocks(int(cap))
+        if os.environ.get("DTF_GEMM_XCD_SPLITS") == "0":  # A/B switch: split-K tiles dealt round-robin over the XCDs
+            _kernels.dtf_gemm_set_xcd_splits(0)
         if os.environ.get("DTF_GEMM_LEAN") == "0":      # A/B switch: general store phase everywhere
             _kernels.dtf_gemm_set_lean(0)
         rows = os.environ.get("DTF_BN_APPLY")           # A/B switch "rows,nt": items per thread of the batch-norm
