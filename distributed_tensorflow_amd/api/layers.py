@@ -283,7 +283,8 @@ class GlobalAveragePooling2D(Layer):
         return (in_shape[-1],)
 
     def forward(self, x):
-        return x.mean(dim=(2, 3))
+        from ..ops import pool as _pool
+        return _pool.global_avg_pool(x)
 
 
 class BatchNormalization(Layer):

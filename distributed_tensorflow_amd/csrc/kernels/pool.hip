@@ -122,3 +122,65 @@ DTF_API int dtf_maxpool_bwd(const void* gy, const void* idx, void* gx, int N, in
                      (const unsigned short*)gy, (const unsigned char*)idx, (unsigned short*)gx, g);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------- global average pool (the ResNet head)
+// y[n][c] = mean over the HW pixels of x[n][.][c], fp32 accumulation; a thread owns 8 channels of one image and walks
+// the pixels (consecutive lanes read consecutive channels, so every access of a wave is one contiguous row piece).
+// Backward is one streaming pass: dx[n][p][c] = dy[n][c] / HW.
+namespace {
+
+__global__ __launch_bounds__(kBlock) void gap_fwd_kernel(const unsigned short* __restrict__ x,
+                                                         unsigned short* __restrict__ y, int N, int HW, int C,
+                                                         float inv) {
+  const int c8 = C >> 3;
+  const long long total = (long long)N * c8;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+    const long long n = i / c8;
+    const int c = (int)(i - n * c8) << 3;
+    const unsigned short* p = x + (n * HW) * C + c;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < HW; ++q, p += C) {
+      const u16x8 v = *reinterpret_cast<const u16x8*>(p);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += bf16_to_f32(v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] *= inv;
+    store8_bf16(y + n * C + c, acc);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gap_bwd_kernel(const unsigned short* __restrict__ dy,
+                                                         unsigned short* __restrict__ dx, long long total, int HW,
+                                                         int C, float inv) {
+  const int c8 = C >> 3;
+  const long long per_image = (long long)HW * c8;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+    const long long n = i / per_image;
+    const int c = (int)(i % c8) << 3;
+    const u16x8 v = *reinterpret_cast<const u16x8*>(dy + n * C + c);
+    float g[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = bf16_to_f32(v[k]) * inv;
+    store8_bf16(dx + i * 8, g);
+  }
+}
+
+}  // namespace
+
+DTF_API int dtf_gap_fwd(const void* x, void* y, int N, int HW, int C, hipStream_t stream) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 0;
+  if (C % 8) return -1;
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(grid_stream((long long)N * (C / 8), kBlock)), dim3(kBlock), 0, stream,
+                     (const unsigned short*)x, (unsigned short*)y, N, HW, C, 1.f / (float)HW);
+  return (int)hipGetLastError();
+}
+
+DTF_API int dtf_gap_bwd(const void* dy, void* dx, int N, int HW, int C, hipStream_t stream) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 0;
+  if (C % 8) return -1;
+  const long long total = (long long)N * HW * (C / 8);
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_stream(total, kBlock)), dim3(kBlock), 0, stream,
+                     (const unsigned short*)dy, (unsigned short*)dx, total, HW, C, 1.f / (float)HW);
+  return (int)hipGetLastError();
+}

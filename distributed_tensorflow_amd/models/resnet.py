@@ -26,6 +26,7 @@ from ..api.model import Model
 from ..ops import conv as conv_ops
 from ..ops import dense as dense_ops
 from ..ops import norm as norm_ops
+from ..ops import pool as pool_ops
 
 
 class Conv(nn.Module):
@@ -159,7 +160,7 @@ class Classifier(nn.Module):
         self.bias = nn.Parameter(torch.zeros(classes))
 
     def forward(self, x):
-        x = x.mean(dim=(2, 3))
+        x = pool_ops.global_avg_pool(x)
         return dense_ops.linear(x, self.weight, self.bias)
 
     def keras_weights(self):

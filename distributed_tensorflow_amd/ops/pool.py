@@ -1,4 +1,4 @@
-"""Max pooling of channels_last (NHWC) activations.
+"""Max pooling and global average pooling of channels_last (NHWC) activations.
 
 bf16 GPU tensors with a channel count that is a multiple of 8 run on the hand-written kernels of
 ``csrc/kernels/pool.hip`` (forward records the winning tap in one byte per element; backward is
@@ -45,3 +45,33 @@ def max_pool2d(x: torch.Tensor, kernel_size: int, stride: int | None = None, pad
             and x.is_contiguous(memory_format=torch.channels_last)):
         return _MaxPoolFn.apply(x, kernel_size, s, padding)
     return F.max_pool2d(x, kernel_size, s, padding)
+
+
+class _GlobalAvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        y = torch.empty((N, C), dtype=x.dtype, device=x.device)
+        rc = _lib.kernels().dtf_gap_fwd(_lib.ptr(x), _lib.ptr(y), N, H * W, C, _lib.stream_ptr(x.device))
+        _lib.check(rc, "gap_fwd")
+        ctx.geom = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.geom
+        gy = gy.contiguous()
+        gx = torch.empty((N, H, W, C), dtype=gy.dtype, device=gy.device)
+        rc = _lib.kernels().dtf_gap_bwd(_lib.ptr(gy), _lib.ptr(gx), N, H * W, C, _lib.stream_ptr(gy.device))
+        _lib.check(rc, "gap_bwd")
+        return gx.permute(0, 3, 1, 2)
+
+
+def global_avg_pool(x: torch.Tensor) -> torch.Tensor:
+    """``x.mean(dim=(2, 3))`` of an ``[N, C, H, W]`` activation: the head of the ResNets. bf16 channels_last GPU
+    tensors run on ``gap_fwd_kernel`` / ``gap_bwd_kernel`` (fp32 accumulation; the backward pass is one streaming
+    write instead of an expand, a copy and a division)."""
+    if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        return _GlobalAvgPoolFn.apply(x)
+    return x.mean(dim=(2, 3))

@@ -576,6 +576,25 @@ def test_max_pool_matches_torch(cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(5, 2048, 7, 7), (3, 64, 8, 8), (2, 24, 1, 1), (130, 8, 3, 5)])
+def test_global_avg_pool_matches_fp32(cfg):
+    from distributed_tensorflow_amd.ops import pool
+    N, C, H, W = cfg
+    torch.manual_seed(sum(cfg))
+    x = torch.randn(N, C, H, W, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    x1 = x.clone().requires_grad_(True)
+    y = pool.global_avg_pool(x1)
+    ref = x.float().mean(dim=(2, 3))
+    assert y.shape == (N, C) and y.dtype == torch.bfloat16
+    assert torch.allclose(y.float(), ref, atol=4e-3, rtol=8e-3)
+    gy = torch.randn(N, C, device=DEV).bfloat16()
+    y.backward(gy)
+    gref = (gy.float() / (H * W))[:, :, None, None].expand(N, C, H, W)
+    assert x1.grad.shape == x.shape and x1.grad.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(x1.grad.float(), gref, atol=1e-6, rtol=8e-3)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_embedding_table_grad_sorted_runs(dt):
     """Long runs of one id (cut into pieces, combined with atomics) and singletons (plain stores)."""
