@@ -1080,8 +1080,8 @@ DTF_API int dtf_splitk_reduce(const float* W, void* C, const void* bias, int bia
 static int g_xcd_splits = 1;             // split-K weight gradients: tiles of a split on one XCD (measurement hook)
 DTF_API void dtf_gemm_set_xcd_splits(int on) { g_xcd_splits = on != 0; }
 
-static int g_lean = 1;                   // lean store phase where it applies (measurement hook: 0 = never)
-DTF_API void dtf_gemm_set_lean(int on) { g_lean = on != 0; }
+static int g_lean = 1;                   // lean store phase where it applies (measurement hook: 0 = never,
+DTF_API void dtf_gemm_set_lean(int on) { g_lean = on; }   // 1 = everywhere, 2 = plain products only)
 
 static int g_stages = 0;                 // 0 = automatic
 constexpr int kSingleStageTiles = 1 << 20;   // in effect always: one buffer also measured faster on the long weight-gradient loops
@@ -1214,16 +1214,22 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   const size_t lds = (stages == 2 ? 2 : 1) * stage_bytes;
   // the lean store-phase variant that matches the request exactly (0 = none does: the general kernel)
   int epi = 0;
-  if (g_lean && splits == 1 && !bias && act == 0 && !g.drop_thresh && !out_fp32 && !g.up2 && stages == 1 && conv == 0 &&
-      layout != 2 && !g.tf_scale && batch == 1) {
+  // (the 128x128 form of the stride-1 data gradient spills with the look-ahead of the lean store phase and measured
+  // slower with it, 469 vs 330 us per call: it keeps the general one)
+  const bool lean_conv = (conv == 0 && layout != 2) || (g_lean == 1 && conv == 1 && layout == 0) ||
+                         (g_lean == 1 && conv == 2 && layout == 1 && c.S == 1 && variant == 1);
+  if (g_lean && splits == 1 && !bias && act == 0 && !g.drop_thresh && !out_fp32 && !g.up2 && stages == 1 && lean_conv &&
+      !g.tf_scale && batch == 1) {
     epi = 1 | (g.col_stats && g.stats_mode == 0 ? 2 : 0) | (g.Cin ? 4 : 0) | (g.col_stats && g.stats_mode == 1 ? 8 : 0);
-    const bool have = layout == 0 ? (epi == 1 || epi == 3) : (epi == 1 || epi == 5 || epi == 9 || epi == 13);
+    const bool have = conv == 1 ? (epi == 1 || epi == 3)
+                    : conv == 2 ? (epi == 1 || epi == 9)
+                    : layout == 0 ? (epi == 1 || epi == 3) : (epi == 1 || epi == 5 || epi == 9 || epi == 13);
     if (!have) epi = 0;
   }
-#define GEMM_LEAN(BT, E)                                                                                       \
+#define GEMM_LEAN(BT, CV, E)                                                                                   \
   do {                                                                                                         \
-    if (variant) hipLaunchKernelGGL((gemm_bf16_kernel<0, BT, 0, 1, 1, 0, E>), grid, dim3(kThreads), lds, stream, g); \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<0, BT, 0, 1, 0, 0, E>), grid, dim3(kThreads), lds, stream, g);     \
+    if (variant) hipLaunchKernelGGL((gemm_bf16_kernel<0, BT, CV, 1, 1, 0, E>), grid, dim3(kThreads), lds, stream, g); \
+    else if (CV != 2) hipLaunchKernelGGL((gemm_bf16_kernel<0, BT, CV == 2 ? 0 : CV, 1, 0, 0, E>), grid, dim3(kThreads), lds, stream, g); \
   } while (0)
 #define GEMM_LAUNCH(AT, BT, CV)                                                                              \
   do {                                                                                                       \
@@ -1243,13 +1249,17 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
     else if (layout == 2 && conv == 3) GEMM_LAUNCH_TF(1, 1, 3, 2);
     else GEMM_LAUNCH_TF(1, 1, 4, 1);
   } else if (epi) {
-    switch (layout * 16 + epi) {
-      case 1: GEMM_LEAN(0, 1); break;
-      case 3: GEMM_LEAN(0, 3); break;
-      case 16 + 1: GEMM_LEAN(1, 1); break;
-      case 16 + 5: GEMM_LEAN(1, 5); break;
-      case 16 + 9: GEMM_LEAN(1, 9); break;
-      case 16 + 13: GEMM_LEAN(1, 13); break;
+    switch (conv * 64 + layout * 16 + epi) {
+      case 1: GEMM_LEAN(0, 0, 1); break;
+      case 3: GEMM_LEAN(0, 0, 3); break;
+      case 16 + 1: GEMM_LEAN(1, 0, 1); break;
+      case 16 + 5: GEMM_LEAN(1, 0, 5); break;
+      case 16 + 9: GEMM_LEAN(1, 0, 9); break;
+      case 16 + 13: GEMM_LEAN(1, 0, 13); break;
+      case 64 + 1: GEMM_LEAN(0, 1, 1); break;
+      case 64 + 3: GEMM_LEAN(0, 1, 3); break;
+      case 128 + 16 + 1: GEMM_LEAN(1, 2, 1); break;
+      case 128 + 16 + 9: GEMM_LEAN(1, 2, 9); break;
       default: return -1;
     }
   } else if (conv == 0) {

@@ -54,8 +54,8 @@ def kernels() -> ctypes.CDLL:
             _kernels.dtf_set_stream_blocks(int(cap))
         if os.environ.get("DTF_GEMM_XCD_SPLITS") == "0":  # A/B switch: split-K tiles dealt round-robin over the XCDs
             _kernels.dtf_gemm_set_xcd_splits(0)
-        if os.environ.get("DTF_GEMM_LEAN") == "0":      # A/B switch: general store phase everywhere
-            _kernels.dtf_gemm_set_lean(0)
+        if os.environ.get("DTF_GEMM_LEAN"):             # A/B switch: 0 = general store phase everywhere,
+            _kernels.dtf_gemm_set_lean(int(os.environ["DTF_GEMM_LEAN"]))   # 2 = lean for plain products only
         rows = os.environ.get("DTF_BN_APPLY")           # A/B switch "rows,nt": items per thread of the batch-norm
         if rows:                                        # apply kernels, non-temporal loads on / off
             r, nt = rows.split(",")
