@@ -23,7 +23,9 @@ from . import _lib
 _ACT = {None: 0, "relu": 1, "gelu": 2}
 NT, NN, TN = 0, 1, 2
 _N_CU = 256
-_SPLIT_BLOCKS_PER_CU = int(os.environ.get("DTF_GEMM_SPLIT_BLOCKS_PER_CU", "4"))   # split-K target for products of <= 16 tiles (4 measured 1 % above 3 on ResNet-50)
+_SPLIT_BLOCKS_WIDE = int(os.environ.get("DTF_GEMM_SPLIT_BLOCKS_WIDE", "4"))       # ... and for wider ones
+_SPLIT_BLOCKS_PER_CU = int(os.environ.get("DTF_GEMM_SPLIT_BLOCKS_PER_CU", "6"))   # split-K target for products of <= 16 tiles
+# (with the blocks of a split sharing an XCD: 6 / 4 measured 76.0 ms per ResNet-50 step, 4 / 3 77.0, 8 / 4 75.9, 12 / 6 76.5)
 
 
 def _ok2d(t: torch.Tensor) -> bool:
@@ -130,7 +132,7 @@ def _pick_splits(M: int, N: int, K: int) -> int:
         return 1
     # few output tiles and a very long contraction (convolution weight gradients over a large batch) are pure
     # streaming: one more resident block per CU hides more latency; wider outputs measured better with 3
-    per_cu = _SPLIT_BLOCKS_PER_CU if tiles <= 16 else 3
+    per_cu = _SPLIT_BLOCKS_PER_CU if tiles <= 16 else _SPLIT_BLOCKS_WIDE
     want = -(-per_cu * _N_CU // tiles)
     return max(1, min(want, K // 512, 512))
 
