@@ -627,7 +627,14 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 3) void gemm_bf16_kernel(GemmArgs
   for (int j = 0; j < (EPI ? 0 : 4); ++j) {
     const int n = wn0 + j * 16 + fq * 4;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && n < g.N) {
+    if (g.bias && n < g.N && n + 4 > g.N) {
+      // the last columns of a product whose width is not a multiple of 4: element by element, nothing read past N
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < g.N)
+          bv[r] = g.bias_dtype == 0 ? reinterpret_cast<const float*>(g.bias)[n + r]
+                                    : bf16_to_f32(reinterpret_cast<const unsigned short*>(g.bias)[n + r]);
+    } else if (g.bias && n < g.N) {
       if (g.bias_dtype == 0) {
         f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.bias) + n);
         bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];

@@ -72,13 +72,14 @@ __device__ __forceinline__ void online1(float x, int idx, float& m, float& s, in
 template <typename T, typename L, int LPR>
 __global__ __launch_bounds__(kBlock) void softmax_ce_fwd_kernel(const T* __restrict__ x, const L* __restrict__ y,
                                                                 float* __restrict__ loss, float* __restrict__ lse_out,
-                                                                unsigned char* __restrict__ correct, int B, int C) {
+                                                                unsigned char* __restrict__ correct, int B, int C,
+                                                                long long ld) {
   constexpr int V = Elt<T>::V;
   constexpr int RPB = kBlock / LPR;  // rows per block
   const int sub = threadIdx.x % LPR;
   const long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPR;
   const bool live = row < B;
-  const T* xr = x + (live ? row : 0) * (long long)C;
+  const T* xr = x + (live ? row : 0) * ld;
 
   float m = -INFINITY, s = 0.f;
   int am = 0;
@@ -125,14 +126,14 @@ template <typename T, typename L, int LPR>
 __global__ __launch_bounds__(kBlock) void softmax_ce_bwd_kernel(const T* __restrict__ x, const L* __restrict__ y,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ gout, T* __restrict__ dx,
-                                                                int B, int C) {
+                                                                int B, int C, long long ld) {
   constexpr int V = Elt<T>::V;
   constexpr int RPB = kBlock / LPR;
   const int sub = threadIdx.x % LPR;
   const long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPR;
   if (row >= B) return;
-  const T* xr = x + row * (long long)C;
-  T* dr = dx + row * (long long)C;
+  const T* xr = x + row * ld;
+  T* dr = dx + row * ld;
   const long long lab = (long long)y[row];
   const bool ignored = !(lab >= 0 && lab < C);
   const float g = ignored ? 0.f : gout[row];
@@ -157,15 +158,18 @@ __global__ __launch_bounds__(kBlock) void softmax_ce_bwd_kernel(const T* __restr
   }
   for (int i = head + nvec * V + sub; i < C; i += LPR)
     Elt<T>::st(dr + i, g * (__expf(Elt<T>::ld(xr + i) - l) - (i == labi ? 1.f : 0.f)));
+  // padded rows (ld > C): the padding of the gradient is zeroed, so that a GEMM may read whole 16-byte chunks
+  for (long long i = C + sub; i < ld; i += LPR) Elt<T>::st(dr + i, 0.f);
 }
 
-// x_dtype: 0 fp32, 1 bf16. label_dtype: 0 int32, 1 int64.
-DTF_API int dtf_softmax_ce_fwd(const void* x, const void* y, float* loss, float* lse, unsigned char* correct,
-                               int B, int C, int x_dtype, int label_dtype, hipStream_t stream) {
+// x_dtype: 0 fp32, 1 bf16. label_dtype: 0 int32, 1 int64. ld: row stride of x (and dx) in elements, >= C.
+DTF_API int dtf_softmax_ce_fwd_ld(const void* x, const void* y, float* loss, float* lse, unsigned char* correct,
+                                  int B, int C, long long ld, int x_dtype, int label_dtype, hipStream_t stream) {
   if (B <= 0 || C <= 0) return 0;
+  if (ld < C) return -1;
 #define FWD(T, L, LPR)                                                                                        \
   hipLaunchKernelGGL((softmax_ce_fwd_kernel<T, L, LPR>), dim3((B + (kBlock / LPR) - 1) / (kBlock / LPR)),    \
-                     dim3(kBlock), 0, stream, (const T*)x, (const L*)y, loss, lse, correct, B, C)
+                     dim3(kBlock), 0, stream, (const T*)x, (const L*)y, loss, lse, correct, B, C, ld)
   const bool small = C <= 64;
   if (x_dtype == 0 && label_dtype == 0) { if (small) FWD(float, int, 8); else FWD(float, int, 64); }
   else if (x_dtype == 0) { if (small) FWD(float, long long, 8); else FWD(float, long long, 64); }
@@ -175,13 +179,19 @@ DTF_API int dtf_softmax_ce_fwd(const void* x, const void* y, float* loss, float*
   return (int)hipGetLastError();
 }
 
-DTF_API int dtf_softmax_ce_bwd(const void* x, const void* y, const float* lse, const float* gout, void* dx,
+DTF_API int dtf_softmax_ce_fwd(const void* x, const void* y, float* loss, float* lse, unsigned char* correct,
                                int B, int C, int x_dtype, int label_dtype, hipStream_t stream) {
+  return dtf_softmax_ce_fwd_ld(x, y, loss, lse, correct, B, C, C, x_dtype, label_dtype, stream);
+}
+
+DTF_API int dtf_softmax_ce_bwd_ld(const void* x, const void* y, const float* lse, const float* gout, void* dx,
+                                  int B, int C, long long ld, int x_dtype, int label_dtype, hipStream_t stream) {
   if (B <= 0 || C <= 0) return 0;
+  if (ld < C) return -1;
   if ((reinterpret_cast<uintptr_t>(x) & 15) != (reinterpret_cast<uintptr_t>(dx) & 15)) return -2;
 #define BWD(T, L, LPR)                                                                                        \
   hipLaunchKernelGGL((softmax_ce_bwd_kernel<T, L, LPR>), dim3((B + (kBlock / LPR) - 1) / (kBlock / LPR)),    \
-                     dim3(kBlock), 0, stream, (const T*)x, (const L*)y, lse, gout, (T*)dx, B, C)
+                     dim3(kBlock), 0, stream, (const T*)x, (const L*)y, lse, gout, (T*)dx, B, C, ld)
   const bool small = C <= 64;
   if (x_dtype == 0 && label_dtype == 0) { if (small) BWD(float, int, 8); else BWD(float, int, 64); }
   else if (x_dtype == 0) { if (small) BWD(float, long long, 8); else BWD(float, long long, 64); }
@@ -189,4 +199,9 @@ DTF_API int dtf_softmax_ce_bwd(const void* x, const void* y, const float* lse, c
   else { if (small) BWD(unsigned short, long long, 8); else BWD(unsigned short, long long, 64); }
 #undef BWD
   return (int)hipGetLastError();
+}
+
+DTF_API int dtf_softmax_ce_bwd(const void* x, const void* y, const float* lse, const float* gout, void* dx,
+                               int B, int C, int x_dtype, int label_dtype, hipStream_t stream) {
+  return dtf_softmax_ce_bwd_ld(x, y, lse, gout, dx, B, C, C, x_dtype, label_dtype, stream);
 }

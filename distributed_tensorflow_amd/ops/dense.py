@@ -87,6 +87,61 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+def _padded_cols(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+class _LinearPadNFn(torch.autograd.Function):
+    """bf16 layer whose output width is not a multiple of 8 (BERT's 30522-word vocabulary projection): the output
+    lives in a buffer with rows padded to 16 bytes and the MFMA kernel runs all three products. Forward: rows of the
+    weight past N read as zeros (range check of the buffer descriptor) and whole 16-byte chunks are stored, so the
+    padding columns hold zeros. Backward: the gradient arrives in the same padded layout with zeroed padding (the
+    fused softmax-cross-entropy produces it so) or is copied into it; the data gradient then contracts over N reading
+    whole chunks of the gradient against zero rows of the weight, and the weight gradient stores N rows."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        K, N = x.shape[-1], w.shape[0]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M, Np = x2.shape[0], _padded_cols(N)
+        buf = torch.empty((M, Np), dtype=torch.bfloat16, device=x.device)
+        _gemm.gemm_raw(_gemm.NT, x2, w, buf, M, N, K, K, K, Np, bias=b)
+        ctx.bias_dtype = b.dtype if b is not None else None
+        ctx.x_shape = x.shape
+        ctx.save_for_backward(x2, w)
+        return buf.view(*x.shape[:-1], Np)[..., :N]
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w = ctx.saved_tensors
+        N, K = w.shape
+        M, Np = x2.shape[0], _padded_cols(N)
+        g = gy.reshape(-1, N) if gy.dim() != 2 else gy
+        # a [M, N] window of a buffer of exactly M rows of Np elements: the padded layout this function (and the
+        # fused loss downstream) produce. Its padding columns are ours to clear.
+        owns_padding = (g.dtype == torch.bfloat16 and g.stride() == (Np, 1) and g.storage_offset() == 0
+                        and g.untyped_storage().nbytes() == M * Np * 2 and g.data_ptr() % 16 == 0)
+        if owns_padding:
+            full = g.as_strided((M, Np), (Np, 1))
+            full[:, N:].zero_()
+        else:
+            full = torch.zeros((M, Np), dtype=torch.bfloat16, device=g.device)
+            full[:, :N].copy_(g)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((M, K), dtype=torch.bfloat16, device=g.device)
+            _gemm.gemm_raw(_gemm.NN, full, w, gx, M, K, N, Np, K, K)
+            gx = gx.reshape(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty((N, K), dtype=torch.bfloat16, device=g.device)
+            _gemm.gemm_raw(_gemm.TN, full, x2, gw, N, K, M, Np, K, K)
+        if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
+            gb = _gemm.col_sum(full, dtype=torch.float32)[:N].to(ctx.bias_dtype)
+        return gx, gw, gb
+
+
 class _LinearAnyFn(torch.autograd.Function):
     """GPU path of everything the bf16 tile kernel does not take (fp32 layers, unaligned rows): the three products
     on the general-purpose MFMA GEMM, which reads the operands through their strides (no transposed copies)."""
@@ -233,6 +288,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = No
     p = float(dropout_p) if training else 0.0
     if x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and _gemm.supported(x, weight):
         return _LinearFn.apply(x, weight, bias, activation, p)
+    if (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and activation is None and p == 0.0
+            and weight.shape[0] % 8 and weight.shape[0] >= 64 and _gemm.supported(x, weight, any_width=True)):
+        return _LinearPadNFn.apply(x, weight, bias)
     if x.is_cuda and weight.is_cuda and x.numel() > 0 and x.dtype in (torch.float32, torch.bfloat16) \
             and weight.dtype in (torch.float32, torch.bfloat16):
         return _LinearAnyFn.apply(x, weight, bias, activation, p)

@@ -33,11 +33,12 @@ def _ok2d(t: torch.Tensor) -> bool:
             and t.data_ptr() % 16 == 0 and t.shape[1] % 8 == 0)
 
 
-def supported(x: torch.Tensor, w: torch.Tensor) -> bool:
-    """True when ``x[..., K] @ w[N, K]^T`` and both of its gradients can run on the MFMA kernel."""
+def supported(x: torch.Tensor, w: torch.Tensor, any_width: bool = False) -> bool:
+    """True when ``x[..., K] @ w[N, K]^T`` and both of its gradients can run on the MFMA kernel. ``any_width``: N need
+    not be a multiple of 8 (the caller keeps the output in a buffer with padded rows, ``ops.dense._LinearPadNFn``)."""
     K = x.shape[-1]
     N = w.shape[0]
-    return (x.is_cuda and K % 8 == 0 and N % 8 == 0 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    return (x.is_cuda and K % 8 == 0 and (N % 8 == 0 or any_width) and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
             and w.is_contiguous() and x.numel() > 0
             # operands are addressed with 32-bit byte offsets (buffer descriptors): below 2^31 elements each
             and x.numel() < (1 << 31) and w.numel() < (1 << 31) and (x.numel() // K) * N < (1 << 31))
@@ -146,8 +147,8 @@ def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, s
         ldc = out.stride(0)
         if out.stride(1) != 1:
             raise ValueError("gemm output must be row-major")
-    if N % 8 or ldc % 8 or out.data_ptr() % 16:
-        raise ValueError("gemm output needs N % 8 == 0 and a 16-byte aligned row-major buffer")
+    if ldc % 8 or ldc < (N + 7) // 8 * 8 or out.data_ptr() % 16:
+        raise ValueError("gemm output needs 16-byte aligned rows that hold N rounded up to a multiple of 8 elements")
     batch = 1
     if tile_variant(N):
         if extra is None:

@@ -13,6 +13,8 @@ a parity option for 10-class outputs, not a hot path.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -26,17 +28,23 @@ def _label_code(y: torch.Tensor) -> int:
     raise TypeError("labels must be int32 or int64")
 
 
+def _row_padded(t: torch.Tensor) -> bool:
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.shape[0] > 0
+
+
 def _fwd(logits: torch.Tensor, labels: torch.Tensor, want_correct: bool):
     B, C = logits.shape
     if logits.is_cuda:
-        x = logits.contiguous()
+        # rows may be padded (stride(0) > C): the logits of a vocabulary whose size is not a multiple of 8 come in a
+        # buffer with 16-byte aligned rows (ops.dense.linear), and are read in place
+        x = logits if _row_padded(logits) else logits.contiguous()
         y = labels.contiguous()
         loss = torch.empty(B, dtype=torch.float32, device=x.device)
         lse = torch.empty(B, dtype=torch.float32, device=x.device)
         correct = torch.empty(B, dtype=torch.uint8, device=x.device) if want_correct else None
-        rc = _lib.kernels().dtf_softmax_ce_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(loss), _lib.ptr(lse),
-                                               _lib.ptr(correct), B, C, _lib.dtype_code(x.dtype), _label_code(y),
-                                               _lib.stream_ptr(x.device))
+        rc = _lib.kernels().dtf_softmax_ce_fwd_ld(_lib.ptr(x), _lib.ptr(y), _lib.ptr(loss), _lib.ptr(lse),
+                                                  _lib.ptr(correct), B, C, ctypes.c_longlong(x.stride(0)),
+                                                  _lib.dtype_code(x.dtype), _label_code(y), _lib.stream_ptr(x.device))
         _lib.check(rc, "softmax_ce_fwd")
         return x, y, loss, lse, correct
     xf = logits.float()
@@ -61,10 +69,12 @@ class _SoftmaxCE(torch.autograd.Function):
         B, C = x.shape
         g = gout.contiguous().float()
         if x.is_cuda:
-            dx = torch.empty_like(x)
-            rc = _lib.kernels().dtf_softmax_ce_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(lse), _lib.ptr(g), _lib.ptr(dx),
-                                                   B, C, _lib.dtype_code(x.dtype), _label_code(y),
-                                                   _lib.stream_ptr(x.device))
+            ld = x.stride(0)
+            # same row padding as the logits; the kernel zeroes the padding of the gradient
+            dx = torch.empty((B, ld), dtype=x.dtype, device=x.device)[:, :C]
+            rc = _lib.kernels().dtf_softmax_ce_bwd_ld(_lib.ptr(x), _lib.ptr(y), _lib.ptr(lse), _lib.ptr(g), _lib.ptr(dx),
+                                                      B, C, ctypes.c_longlong(ld), _lib.dtype_code(x.dtype),
+                                                      _label_code(y), _lib.stream_ptr(x.device))
             _lib.check(rc, "softmax_ce_bwd")
             return dx, None
         valid = ((y >= 0) & (y < C))

@@ -576,6 +576,38 @@ def test_max_pool_matches_torch(cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(300, 64, 1002), (1000, 768, 3054), (64, 128, 67)])
+def test_linear_unaligned_width_runs_on_the_bf16_kernel_with_padded_rows(cfg):
+    """A bf16 layer whose width is not a multiple of 8 (BERT's vocabulary projection) followed by the fused loss:
+    logits and their gradient stay in row-padded buffers; values and all gradients against an fp32 evaluation."""
+    from distributed_tensorflow_amd.ops import dense
+    from distributed_tensorflow_amd.ops.softmax_ce import softmax_cross_entropy
+    M, K, N = cfg
+    torch.manual_seed(M + N)
+    x = (torch.randn(M, K, device=DEV) * 0.5).bfloat16().requires_grad_(True)
+    w = (torch.randn(N, K, device=DEV) * 0.05).bfloat16().requires_grad_(True)
+    b = (torch.randn(N, device=DEV) * 0.1).requires_grad_(True)
+    y = torch.randint(0, N, (M,), device=DEV)
+    logits = dense.linear(x, w, b)
+    assert logits.shape == (M, N) and logits.stride(0) % 8 == 0 and logits.stride(0) >= N     # padded rows
+    loss = softmax_cross_entropy(logits, y, reduction="mean")
+    loss.backward()
+    xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+    lr = torch.nn.functional.cross_entropy(xr @ wr.t() + br, y)
+    lr.backward()
+    assert torch.allclose(logits.float(), (xr @ wr.t() + br).detach(), atol=3e-2, rtol=2e-2)
+    assert abs(float(loss) - float(lr)) < 2e-2
+    for got, ref in ((x.grad, xr.grad), (w.grad, wr.grad), (b.grad, br.grad)):
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((got.float() - ref).abs().max()) < 3e-2 * scale
+    # a gradient that does not come in the padded layout (here: a plain sum) is copied into it
+    x2 = x.detach().clone().requires_grad_(True)
+    dense.linear(x2, w.detach(), None).float().sum().backward()
+    ref = w.detach().float().sum(0)[None, :].expand(M, K)
+    assert torch.allclose(x2.grad.float(), ref, atol=0.05 * float(ref.abs().max()), rtol=3e-2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(5, 2048, 7, 7), (3, 64, 8, 8), (2, 24, 1, 1), (130, 8, 3, 5)])
 def test_global_avg_pool_matches_fp32(cfg):
     from distributed_tensorflow_amd.ops import pool
