@@ -23,6 +23,11 @@ from ..ops import bucket as bops
 from .flat import Bucket, BucketPlanner, FlatParams
 
 
+def _side_grads():
+    from ..ops.conv import side_grads
+    return side_grads
+
+
 class GradReducer:
     def __init__(self, flat: FlatParams, planner: BucketPlanner,
                  on_ready: Callable[[Bucket], Any] | None = None, grad_scale: float = 1.0):
@@ -55,6 +60,7 @@ class GradReducer:
         self._next = 0
         self.works = [None] * len(self.planner.buckets)
         self._in_step = True
+        _side_grads().open()               # weight gradients may run on a side stream until finish()
 
     def _hook(self, param: torch.Tensor) -> None:
         if not (self.enabled and self._in_step):
@@ -97,6 +103,10 @@ class GradReducer:
     def _pack(self, b: Bucket) -> None:
         flat = self.flat
         grads = [s.param.grad for s in b.slots]
+        side = _side_grads()
+        for g in grads:                    # gradients computed on the side stream: wait for their kernels
+            if g is not None:
+                side.wait(g)
         g0 = grads[0]
         if flat.grad.is_cuda and g0 is not None and all(g is not None and g.dtype == g0.dtype for g in grads):
             # fast path (every step of an ordinary run): all gradients present, one dtype
@@ -142,5 +152,6 @@ class GradReducer:
         for i in range(len(self._ready)):
             self._ready[i] = True
         self._drain()
+        _side_grads().close()
         self._in_step = False
         return self.works

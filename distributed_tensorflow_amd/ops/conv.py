@@ -60,6 +60,69 @@ def get_convkxk_backend() -> str:
     return _backend_kxk
 
 
+class _SideGrads:
+    """Weight gradients on a second stream.
+
+    A weight gradient is needed by nobody until the gradient bucket it belongs to is packed, while the data gradient
+    next to it is on the critical path of the backward pass. Between ``open()`` and ``close()`` (the gradient
+    reducer brackets a training step with them) ``run(fn, inputs)`` launches ``fn`` on a side stream that first
+    waits for everything the main stream has queued so far, and remembers an event per result; ``wait(tensor)``
+    makes the current stream wait for the kernels that produce ``tensor``. The weight-gradient GEMMs (MFMA and issue
+    bound) then share the GPU with the memory-bound norm and data-gradient kernels of the layers before them.
+    Outside the bracket, during hipGraph capture and on the CPU ``run`` just calls ``fn``.
+    """
+
+    def __init__(self):
+        self.enabled = os.environ.get("DTF_WGRAD_STREAM", "1") == "1"     # A/B switch; 76.3 -> 74.9 ms per ResNet-50 step
+        self._open = False
+        self._streams: dict = {}
+        self._events: dict = {}
+        self._held: list = []
+
+    def open(self) -> None:
+        self._open = self.enabled
+        self._events.clear()
+
+    def run(self, fn, out: torch.Tensor, keep) -> None:
+        """``fn()`` launches the kernels that fill ``out`` (allocated by the caller, on the main stream, so that the
+        caching allocator orders its reuse after the main-stream kernels that read it). ``keep``: every tensor the
+        kernels read; held here until the side stream is done with them -- a reference, not ``record_stream``,
+        which made the allocator of a 100 GB step poll thousands of events and measured five times slower."""
+        dev = out.device
+        if not (self._open and dev.type == "cuda") or torch.cuda.is_current_stream_capturing():
+            fn()
+            return
+        side = self._streams.get(dev)
+        if side is None:
+            side = self._streams[dev] = torch.cuda.Stream(dev)      # (a lower stream priority measured no different)
+        main = torch.cuda.current_stream(dev)
+        side.wait_event(main.record_event())
+        with torch.cuda.stream(side):
+            fn()
+            done = side.record_event()
+        self._events[out.data_ptr()] = done
+        self._held = [h for h in self._held if not h[0].query()]
+        self._held.append((done, keep, out))
+
+    def wait(self, t: torch.Tensor) -> None:
+        ev = self._events.pop(t.data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream(t.device).wait_event(ev)
+
+    def close(self) -> None:
+        """Every outstanding result becomes visible to the current streams."""
+        for dev, side in self._streams.items():
+            if self._events or self._held:
+                torch.cuda.current_stream(dev).wait_stream(side)
+        self._events.clear()
+        # the main stream now runs after everything the side stream did: frees are ordered behind it
+        self._held.clear()
+        self._open = False
+
+
+side_grads = _SideGrads()
+
+
 class _ConvFn(torch.autograd.Function):
     """k x k convolution (stride 1 or 2) as three implicit-GEMM launches on the NHWC bytes: the image
     operand is gathered pixel by pixel while it is staged into LDS, so there is no im2col buffer, no
@@ -169,20 +232,32 @@ class _ConvFn(torch.autograd.Function):
         if g_alias is not None and ctx.needs_input_grad[0]:
             gx = g_alias if gx is None else gx + g_alias
         if want_w:
-            gw = torch.empty((K, KH, KW, C), dtype=w.dtype, device=x.device)
             in_bn = ctx.in_bn         # the activation operand is a deferred norm's input: normalised while staged
-            if plain:
-                _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, C, in_bn=in_bn)
-            elif K <= 64 and _wgrad_t:
-                # narrow layer: the transposed product, every tap side by side in the rows (dy is re-read once per
-                # 128 of them instead of once per tap)
-                ex = _gemm.conv_geom(_gemm.CONV_WGRAD_T, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
-                gwt = torch.empty((KH * KW * C, K), dtype=w.dtype, device=x.device)
-                _gemm.gemm_raw(_gemm.TN, x, gy, gwt, KH * KW * C, K, N * OH * OW, C, K, K, extra=ex, in_bn=in_bn)
-                gw = gwt.t().contiguous().view(K, KH, KW, C)
+
+            transposed = (not plain) and K <= 64 and _wgrad_t
+            gw = torch.empty((K, KH, KW, C), dtype=w.dtype, device=x.device)
+            gwt = torch.empty((KH * KW * C, K), dtype=w.dtype, device=x.device) if transposed else None
+
+            def weight_gradient():
+                if plain:
+                    _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, C, in_bn=in_bn)
+                elif transposed:
+                    # narrow layer: the transposed product, every tap side by side in the rows (dy is re-read once
+                    # per 128 of them instead of once per tap)
+                    ex = _gemm.conv_geom(_gemm.CONV_WGRAD_T, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
+                    _gemm.gemm_raw(_gemm.TN, x, gy, gwt, KH * KW * C, K, N * OH * OW, C, K, K, extra=ex, in_bn=in_bn)
+                    gw.view(K, KH * KW * C).copy_(gwt.t())
+                else:
+                    ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
+                    _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex, in_bn=in_bn)
+
+            # (on the side stream only when autograd will keep the very tensor as the parameter's gradient: a weight
+            # in another memory format gets a converted copy, made on the main stream before the side stream has
+            # written the source)
+            if w.is_contiguous(memory_format=torch.channels_last):
+                side_grads.run(weight_gradient, gw, (gy, x, gwt, in_bn))
             else:
-                ex = _gemm.conv_geom(_gemm.CONV_WGRAD, H, W, OH, OW, stride, padding, KH, KW, C, K, N)
-                _gemm.gemm_raw(_gemm.TN, gy, x, gw, K, C, N * OH * OW, K, C, KH * KW * C, extra=ex, in_bn=in_bn)
+                weight_gradient()
             gw = gw.permute(0, 3, 1, 2)        # [K, C, KH, KW] with channels_last strides
         return gx, gw, None, None, None, None, None, gb, None, None, None, None, None
 

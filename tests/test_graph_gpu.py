@@ -107,3 +107,37 @@ def test_training_is_bit_identical_across_runs_with_a_fixed_seed(model_name):
     assert w1.keys() == w2.keys()
     for k in w1:
         assert torch.equal(w1[k], w2[k]), k
+
+
+def test_weight_gradients_on_the_side_stream_change_nothing():
+    """Weight gradients run on a second stream between the reducer's begin_step() and finish(); a training run
+    with them there must equal the run with everything on one stream, bit for bit."""
+    from distributed_tensorflow_amd.comm.backend import Comm
+    from distributed_tensorflow_amd.engine.optimizer import SGD
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.models.resnet import resnet20
+    from distributed_tensorflow_amd.ops import conv
+    from distributed_tensorflow_amd.parallel.mirrored import MirroredStrategy
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(96, 32, 32, 3, generator=g).to(dev).bfloat16(), torch.randint(0, 10, (96,), generator=g).to(dev))
+               for _ in range(6)]
+    results = []
+    was = conv.side_grads.enabled
+    try:
+        for side in (False, True):
+            conv.side_grads.enabled = side
+            torch.manual_seed(0)
+            cfg = TrainConfig(param_dtype=torch.bfloat16, grad_dtype=torch.bfloat16)
+            st = MirroredStrategy(resnet20(10), Comm(0, 1, dev), cfg, optimizer=SGD(0.05, momentum=0.9))
+            losses = [float(st.train_step(x, y)) for x, y in batches]
+            torch.cuda.synchronize()
+            results.append((losses, st.flat.master.clone()))
+            if side:
+                assert conv.side_grads._streams, "the side stream was never used"
+                assert not conv.side_grads._held and not conv.side_grads._events      # everything handed back
+    finally:
+        conv.side_grads.enabled = was
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])
