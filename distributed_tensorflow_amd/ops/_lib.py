@@ -78,7 +78,21 @@ def dtype_code(t: torch.dtype) -> int:
         raise TypeError(f"unsupported dtype {t}; the kernels take float32 and bfloat16") from None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device=None) -> ctypes.c_void_p:
+    """The current HIP stream of ``device`` as a raw handle. Called once per kernel launch: the raw getter costs a
+    fraction of a microsecond where ``torch.cuda.current_stream`` builds a Python object every time (5 us, a quarter
+    of a millisecond per ResNet-20 step)."""
+    if _raw_stream is not None:
+        if device is None:
+            idx = torch.cuda.current_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+        return ctypes.c_void_p(_raw_stream(idx))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

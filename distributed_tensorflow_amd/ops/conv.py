@@ -121,6 +121,7 @@ class _SideGrads:
 
 
 side_grads = _SideGrads()
+_SIDE_MIN_ELEMS = 1 << 25      # operand elements (gradient + activation) from which a weight gradient takes the side stream
 
 
 class _ConvFn(torch.autograd.Function):
@@ -254,7 +255,9 @@ class _ConvFn(torch.autograd.Function):
             # (on the side stream only when autograd will keep the very tensor as the parameter's gradient: a weight
             # in another memory format gets a converted copy, made on the main stream before the side stream has
             # written the source)
-            if w.is_contiguous(memory_format=torch.channels_last):
+            # ... and only for products large enough to be worth two event calls on the host: a small model's step is
+            # host bound (ResNet-20 at batch 128: 3.7 ms per step without, 5.1 ms with the side stream)
+            if w.is_contiguous(memory_format=torch.channels_last) and gy.numel() + x.numel() >= _SIDE_MIN_ELEMS:
                 side_grads.run(weight_gradient, gw, (gy, x, gwt, in_bn))
             else:
                 weight_gradient()

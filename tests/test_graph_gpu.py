@@ -124,7 +124,8 @@ def test_weight_gradients_on_the_side_stream_change_nothing():
     batches = [(torch.randn(96, 32, 32, 3, generator=g).to(dev).bfloat16(), torch.randint(0, 10, (96,), generator=g).to(dev))
                for _ in range(6)]
     results = []
-    was = conv.side_grads.enabled
+    was, was_min = conv.side_grads.enabled, conv._SIDE_MIN_ELEMS
+    conv._SIDE_MIN_ELEMS = 0          # every weight gradient, however small
     try:
         for side in (False, True):
             conv.side_grads.enabled = side
@@ -138,6 +139,6 @@ def test_weight_gradients_on_the_side_stream_change_nothing():
                 assert conv.side_grads._streams, "the side stream was never used"
                 assert not conv.side_grads._held and not conv.side_grads._events      # everything handed back
     finally:
-        conv.side_grads.enabled = was
+        conv.side_grads.enabled, conv._SIDE_MIN_ELEMS = was, was_min
     assert results[0][0] == results[1][0]
     assert torch.equal(results[0][1], results[1][1])
