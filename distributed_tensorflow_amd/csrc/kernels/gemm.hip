@@ -1222,14 +1222,15 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   // the lean store-phase variant that matches the request exactly (0 = none does: the general kernel)
   int epi = 0;
   // (the 128x128 form of the stride-1 data gradient spills with the look-ahead of the lean store phase and measured
-  // slower with it, 469 vs 330 us per call: it keeps the general one)
+  // slower with it, 469 vs 330 us per call: it keeps the general one. The stride-2 data gradient, whose parity
+  // classes run 1-4 filter taps deep and which carries no statistics, takes the plain lean form in both tiles.)
   const bool lean_conv = (conv == 0 && layout != 2) || (g_lean == 1 && conv == 1 && layout == 0) ||
-                         (g_lean == 1 && conv == 2 && layout == 1 && c.S == 1 && variant == 1);
+                         (g_lean == 1 && conv == 2 && layout == 1);
   if (g_lean && splits == 1 && !bias && act == 0 && !g.drop_thresh && !out_fp32 && !g.up2 && stages == 1 && lean_conv &&
       !g.tf_scale && batch == 1) {
     epi = 1 | (g.col_stats && g.stats_mode == 0 ? 2 : 0) | (g.Cin ? 4 : 0) | (g.col_stats && g.stats_mode == 1 ? 8 : 0);
     const bool have = conv == 1 ? (epi == 1 || epi == 3)
-                    : conv == 2 ? (epi == 1 || epi == 9)
+                    : conv == 2 ? ((epi == 1 && (variant == 1 || c.S == 2)) || (epi == 9 && variant == 1 && c.S == 1))
                     : layout == 0 ? (epi == 1 || epi == 3) : (epi == 1 || epi == 5 || epi == 9 || epi == 13);
     if (!have) epi = 0;
   }
@@ -1265,7 +1266,10 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
       case 16 + 13: GEMM_LEAN(1, 0, 13); break;
       case 64 + 1: GEMM_LEAN(0, 1, 1); break;
       case 64 + 3: GEMM_LEAN(0, 1, 3); break;
-      case 128 + 16 + 1: GEMM_LEAN(1, 2, 1); break;
+      case 128 + 16 + 1:
+        if (variant) GEMM_LEAN(1, 2, 1);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<0, 1, 2, 1, 0, 0, 1>), grid, dim3(kThreads), lds, stream, g);
+        break;
       case 128 + 16 + 9: GEMM_LEAN(1, 2, 9); break;
       default: return -1;
     }

@@ -1,6 +1,7 @@
 """Times forward / data-gradient / weight-gradient of single convolutions, own kernel vs vendor library.
 
-usage: python tools/bench_conv.py [batch]    (ResNet-50 strided and 3x3 shapes, batch 256 by default)
+usage: python tools/bench_conv.py [batch] [--library]    (ResNet-50 strided and 3x3 shapes, batch 256 by default;
+the framework's own kernels, plus the vendor library's for comparison with --library; TF = TFLOP/s)
 """
 import os
 import sys
@@ -27,7 +28,7 @@ def timeit(fn, iters=10, warmup=3):
 
 
 def main():
-    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 256
     shapes = [  # N, CI, H, W, CO, k, stride, pad
         (256, 256, 56, 56, 512, 1, 2, 0), (256, 512, 28, 28, 1024, 1, 2, 0), (256, 1024, 14, 14, 2048, 1, 2, 0),
         (256, 128, 56, 56, 128, 3, 2, 1), (256, 256, 28, 28, 256, 3, 2, 1), (256, 512, 14, 14, 512, 3, 2, 1),
@@ -35,11 +36,16 @@ def main():
         (256, 512, 7, 7, 512, 3, 1, 1),
     ]
     shapes = [(nb,) + t[1:] for t in shapes]
-    print(f"{'shape':44s} {'backend':8s} {'fwd_us':>8s} {'dgrad_us':>9s} {'wgrad_us':>9s}")
+    lines = [f"{'shape (N, CI, H, W, CO, k, stride, pad)':44s} {'backend':8s} {'fwd_us':>8s} {'dgrad_us':>9s} {'wgrad_us':>9s}"
+             f" {'fwd_TF':>7s} {'dgrad_TF':>8s} {'wgrad_TF':>8s}"]
+    print(lines[0])
+    backends = ("gemm", "library") if "--library" in sys.argv else ("gemm",)
     for (N, CI, H, W, CO, k, s, p) in shapes:
         x = torch.randn(N, CI, H, W, device=DEV).bfloat16().to(memory_format=torch.channels_last).requires_grad_(True)
         w = (torch.randn(CO, CI, k, k, device=DEV) * 0.05).bfloat16().to(memory_format=torch.channels_last).requires_grad_(True)
-        for backend in ("gemm", "library"):
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        flop = 2.0 * N * OH * OW * CO * CI * k * k
+        for backend in backends:
             C.set_conv1x1_backend(backend)
             C.set_convkxk_backend(backend)
             xd, wd = x.detach(), w.detach()
@@ -50,8 +56,13 @@ def main():
                 tf = timeit(lambda: C.conv2d(xd, wd, stride=s, padding=p))
             td = timeit(lambda: torch.autograd.grad(yd, x, gy, retain_graph=True))
             tw = timeit(lambda: torch.autograd.grad(yw, w, gy, retain_graph=True))
-            print(f"{str((N, CI, H, W, CO, k, s, p)):44s} {backend:8s} {tf:8.1f} {td:9.1f} {tw:9.1f}", flush=True)
+            lines.append(f"{str((N, CI, H, W, CO, k, s, p)):44s} {backend:8s} {tf:8.1f} {td:9.1f} {tw:9.1f}"
+                         f" {flop / tf / 1e6:7.0f} {flop / td / 1e6:8.0f} {flop / tw / 1e6:8.0f}")
+            print(lines[-1], flush=True)
         del x, w, yd, yw, gy
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/conv_rates_b{nb}.txt", "w") as f:
+        f.write("\n".join(lines) + "\n")
 
 
 if __name__ == "__main__":
