@@ -829,19 +829,52 @@ static bool bn_pool_geom_ok(const BnPoolGeom& g) {
          g.OW == (g.W + 2 * g.P - g.K) / g.S + 1;
 }
 
+DTF_API int dtf_bn_relu_maxpool_fwd_stats(const void* x, void* y, void* idx, const float* gamma, const float* beta,
+                                          float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
+                                          float* shift, const float* col_stats, int n_rows, float* workspace, int N,
+                                          int H, int W, int C, int OH, int OW, int K, int S, int P, float eps,
+                                          float momentum, hipStream_t stream);
+
 // y [N,OH,OW,C] = maxpool(relu(bn(x))), idx = winning taps (kh * K + kw); statistics as dtf_bn_fwd_train.
 // workspace: fp32 [dtf_bn_num_partials(N*H*W, C) * 2 * C]. Returns -1 for an unsupported geometry.
 DTF_API int dtf_bn_relu_maxpool_fwd(const void* x, void* y, void* idx, const float* gamma, const float* beta,
                                     float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
                                     float* shift, float* workspace, int N, int H, int W, int C, int OH, int OW, int K,
                                     int S, int P, float eps, float momentum, hipStream_t stream) {
+  return dtf_bn_relu_maxpool_fwd_stats(x, y, idx, gamma, beta, run_mean, run_var, mean, invstd, scale, shift, nullptr, 0,
+                                       workspace, N, H, W, C, OH, OW, K, S, P, eps, momentum, stream);
+}
+
+// The same with the batch statistics of x already reduced to partial rows by its producer (col_stats: fp32
+// [n_rows][2][C], as for dtf_bn_fwd_train_stats; null: reduced here). workspace: fp32
+// [max(dtf_bn_num_partials(N*H*W, C), 256) * 2 * C].
+DTF_API int dtf_bn_relu_maxpool_fwd_stats(const void* x, void* y, void* idx, const float* gamma, const float* beta,
+                                          float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
+                                          float* shift, const float* col_stats, int n_rows, float* workspace, int N,
+                                          int H, int W, int C, int OH, int OW, int K, int S, int P, float eps,
+                                          float momentum, hipStream_t stream) {
   const BnPoolGeom g = {N, H, W, C, OH, OW, K, S, P};
   if (!bn_pool_geom_ok(g)) return -1;
   const long long M = (long long)N * H * W;
-  const int nb = bn_partials_for(M, C);
-  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nb, 1), dim3(kBlock), 0, stream, (const unsigned short*)x, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb,
+  const float* part = workspace;
+  int np;
+  if (col_stats) {
+    if (n_rows < 1) return -1;
+    part = col_stats;
+    np = n_rows;
+    if (n_rows > kFoldAbove) {
+      const int per = (n_rows + kFoldRows - 1) / kFoldRows;
+      np = (n_rows + per - 1) / per;
+      hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(np, (2 * C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                         col_stats, n_rows, per, 2 * C, workspace);
+      part = workspace;
+    }
+  } else {
+    np = bn_partials_for(M, C);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(np, 1), dim3(kBlock), 0, stream, (const unsigned short*)x, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
+  }
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, part, np,
                      gamma, beta, run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
   const int grid = grid_stream((long long)N * OH, 1);
   if (K == 3 && S == 2 && P == 1)

@@ -193,8 +193,9 @@ class ResNet50(Model):
     def forward(self, x, logits: bool = False):
         x = self.prepare_input(x)
         bn = self.stem_bn            # norm + ReLU + max pool in one pass over the widest activation
-        x = norm_ops.batch_norm_relu_max_pool(self.stem(x), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                              bn.training, bn.momentum, bn.eps, 3, 2, 1)
+        z, st = self.stem(x, bn_stats=True)     # the stem convolution reduces the norm's statistics while it stores z
+        x = norm_ops.batch_norm_relu_max_pool(z, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                              bn.training, bn.momentum, bn.eps, 3, 2, 1, st if bn.training else None)
         x = self.blocks(x)
         y = self.head(x)
         return y if logits else torch.softmax(y.float(), dim=-1)

@@ -286,7 +286,7 @@ class _BNReluPoolFn(torch.autograd.Function):
     """``max_pool(relu(bn(x)))`` without materialising the normalised activation (``csrc/kernels/norm.hip``)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, k, s, p):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, k, s, p, partials=None):
         N, C, H, W = x.shape
         OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         dev = x.device
@@ -295,11 +295,16 @@ class _BNReluPoolFn(torch.autograd.Function):
         stats = torch.empty(4, C, dtype=torch.float32, device=dev)
         lib = _lib.kernels()
         nb = lib.dtf_bn_num_partials(ctypes.c_longlong(N * H * W), C)
-        ws = _scratch(dev, nb * 2 * C)
-        rc = lib.dtf_bn_relu_maxpool_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(idx), _lib.ptr(gamma), _lib.ptr(beta),
-                                         _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
-                                         _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), N, H, W, C, OH, OW, k, s,
-                                         p, ctypes.c_float(eps), ctypes.c_float(momentum), _lib.stream_ptr(dev))
+        ws = _scratch(dev, max(nb, 256) * 2 * C)
+        if partials is not None and (partials.dtype != torch.float32 or partials.dim() != 3
+                                     or tuple(partials.shape[1:]) != (2, C) or not partials.is_contiguous()):
+            raise ValueError("batch_norm_relu_max_pool: partials must be a contiguous fp32 [rows, 2, C] tensor")
+        rc = lib.dtf_bn_relu_maxpool_fwd_stats(_lib.ptr(x), _lib.ptr(y), _lib.ptr(idx), _lib.ptr(gamma), _lib.ptr(beta),
+                                               _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]),
+                                               _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
+                                               _lib.ptr(partials), int(partials.shape[0]) if partials is not None else 0,
+                                               _lib.ptr(ws), N, H, W, C, OH, OW, k, s, p, ctypes.c_float(eps),
+                                               ctypes.c_float(momentum), _lib.stream_ptr(dev))
         _lib.check(rc, "bn_relu_maxpool_fwd")
         ctx.save_for_backward(x, idx, gamma, stats)
         ctx.geom = (N, C, H, W, OH, OW, k, s, p)
@@ -323,19 +328,22 @@ class _BNReluPoolFn(torch.autograd.Function):
                                          _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(coef), _lib.ptr(ws), N, H, W, C, OH,
                                          OW, k, s, p, _lib.stream_ptr(dev))
         _lib.check(rc, "bn_relu_maxpool_bwd")
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None
 
 
 def batch_norm_relu_max_pool(x, gamma, beta, running_mean, running_var, training: bool, momentum: float = 0.1,
-                             eps: float = 1e-5, kernel_size: int = 3, stride: int = 2, padding: int = 1):
+                             eps: float = 1e-5, kernel_size: int = 3, stride: int = 2, padding: int = 1, partials=None):
     """``max_pool2d(relu(batch_norm(x)))`` -- the end of the ResNet stem. In training on the bf16 GPU path the
     normalised activation (the widest tensor of the network) is never written: the pool normalises its taps on the
-    fly and the norm's backward passes gather the pool's gradient (``DTF_BN_POOL_FUSED=0`` switches this off)."""
+    fly and the norm's backward passes gather the pool's gradient (``DTF_BN_POOL_FUSED=0`` switches this off).
+    ``partials``: the statistics of ``x`` as its convolution reduced them (``ops.conv.conv2d(..., bn_stats=True)``);
+    the separate reduction pass over ``x`` then does not run."""
     C = x.shape[1]
     if (training and _pool_fused and _fast_path(x) and gamma.dtype == torch.float32 and C <= 2048 and 256 % (C // 8) == 0
             and padding < kernel_size):
         return _BNReluPoolFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, kernel_size, stride,
-                                   padding)
+                                   padding, partials)
     from . import pool as _pool
-    y = batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, True, None)
+    y = batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, True, None,
+                       partials if training else None)
     return _pool.max_pool2d(y, kernel_size, stride, padding)

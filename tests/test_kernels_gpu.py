@@ -576,6 +576,32 @@ def test_max_pool_matches_torch(cfg):
 
 
 @pytest.mark.gpu
+def test_stem_norm_pool_takes_the_statistics_of_the_first_convolution():
+    """conv(7x7 / 2, 3 channels) -> norm + ReLU + max pool: the convolution's store phase reduces the norm's statistics;
+    the result must match the path where the norm reduces them itself (and fp32 torch)."""
+    from distributed_tensorflow_amd.ops import conv, norm
+    torch.manual_seed(5)
+    N, H = 6, 64
+    x = torch.randn(N, 3, H, H, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, device=DEV) * 0.1).bfloat16().contiguous(memory_format=torch.channels_last)
+    gamma, beta = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.1
+    outs = []
+    for use in (True, False):
+        rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        z, st = conv.conv2d(x, w, 2, 3, bn_stats=True)
+        assert st is not None
+        y = norm.batch_norm_relu_max_pool(z, gamma, beta, rm, rv, True, 0.1, 1e-5, 3, 2, 1, st if use else None)
+        outs.append((y.float(), rm.clone(), rv.clone()))
+    (ya, ma, va), (yb, mb, vb) = outs
+    assert torch.allclose(ma, mb, atol=1e-4, rtol=1e-4) and torch.allclose(va, vb, atol=1e-4, rtol=1e-3)
+    assert float((ya - yb).abs().max()) <= 0.04            # a bf16 step at the activation's magnitude
+    zr = torch.nn.functional.conv2d(x.float(), w.float(), None, 2, 3)
+    ref = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.batch_norm(
+        zr, None, None, gamma, beta, True, 0.1, 1e-5)), 3, 2, 1)
+    assert torch.allclose(ya, ref, atol=8e-2, rtol=5e-2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(300, 64, 1002), (1000, 768, 3054), (64, 128, 67)])
 def test_linear_unaligned_width_runs_on_the_bf16_kernel_with_padded_rows(cfg):
     """A bf16 layer whose width is not a multiple of 8 (BERT's vocabulary projection) followed by the fused loss:
