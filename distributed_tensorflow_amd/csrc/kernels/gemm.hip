@@ -206,6 +206,16 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rs, bool ok, 
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
 }
 
+// The same load with the LDS as its destination (LDS-DMA, `buffer_load_dwordx4 ... lds`): the 64 lanes of the
+// instruction fill 1 KiB at `lds` (a wave-uniform address) in lane order, lanes out of range write zeros. The data
+// never passes through registers, and not through the VGPR -> LDS store path either, which moves a 16-byte store at a
+// third of the rate the LDS reads run at (and bounds the register-staged main loop on MFMA-heavy shapes).
+typedef __attribute__((address_space(3))) void* lds_dst_t;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, bool ok, unsigned elem_off, char* lds) {
+  const unsigned off = ok ? elem_off * 2u : 0xffffffffu;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_dst_t)lds, 16, (int)off, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Operand stagers. Each thread owns 4 x 16-byte chunks of a tile. Per-row geometry that does not
 // depend on the k-tile is computed once in init() and kept in registers.
@@ -355,6 +365,80 @@ struct Stager {
     }
   }
 
+  // The tile by LDS-DMA (see dma16): no staging registers. A wave's instruction i fills piece w + 4 i ([row][k] image:
+  // 8 rows of 128 bytes) or 4 w + i ([k][row] image: 4 k-rows of 256 bytes); the lane-linear image of a piece is the
+  // swizzled layout when every lane fetches the chunk that belongs at its position, i.e. the XOR of swz_off / swz_t
+  // is applied to the SOURCE index. GATHER 3 (the x operand of a per-tap weight gradient) has no DMA form.
+  __device__ __forceinline__ void dma(const GemmArgs& g, const unsigned short* __restrict__ X, long long ld, int rows,
+                                      int row0, int k0, int kend, int tap, char* lds) {
+    static_assert(GATHER != 3 && !TF, "no LDS-DMA form");
+    const ConvGeom& c = g.cv;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, (int)0xffffffffu, 0x00020000);
+    const unsigned uld = (unsigned)ld;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (T == 0) {
+      // rows as in init(): row0 + ((tid + 256 i) >> 3); LDS slot tid & 7 of that row holds k-chunk slot ^ ((row >> 1) & 7)
+      const int k = k0 + ((((int)threadIdx.x & 7) ^ (((int)threadIdx.x >> 4) & 7)) << 3);
+      const bool kok = k < kend;
+      if (GATHER == 0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int row = row0 + ((threadIdx.x + kThreads * i) >> 3);
+          dma16(rs, row < rows && kok, (unsigned)row * uld + (unsigned)k, lds + (wv + 4 * i) * 1024);
+        }
+      } else if (GATHER == 1) {
+        int t, ci, kh, kw;
+        divmod(kok ? k : 0, c.CI, c.r_ci, t, ci);
+        divmod(t, c.KW, c.r_kw, kh, kw);
+        const int tapo = (kh * c.W + kw) * c.CI + ci;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int ih = ca[i] + kh, iw = cb[i] + kw;
+          const bool ok = rowok[i] && kok && (unsigned)ih < (unsigned)c.H && (unsigned)iw < (unsigned)c.W;
+          dma16(rs, ok, (unsigned)(base[i] + tapo), lds + (wv + 4 * i) * 1024);
+        }
+      } else {                              // GATHER 2
+        int t, co, kh, kw;
+        divmod(kok ? k : 0, c.CO, c.r_co, t, co);
+        divmod(t, c.KW, c.r_kw, kh, kw);
+        if (c.S == 1) {
+          const int tapo = co - (kh * c.OW + kw) * c.CO;
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) {
+            const int th = ca[i] - kh, tw = cb[i] - kw;
+            const bool ok = rowok[i] && kok && (unsigned)th < (unsigned)c.OH && (unsigned)tw < (unsigned)c.OW;
+            dma16(rs, ok, (unsigned)(base[i] + tapo), lds + (wv + 4 * i) * 1024);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) {
+            const int th = ca[i] - kh, tw = cb[i] - kw;
+            const int oh = th >> 1, ow = tw >> 1;
+            const bool ok = rowok[i] && kok && th >= 0 && tw >= 0 && !((th | tw) & 1) && oh < c.OH && ow < c.OW;
+            dma16(rs, ok, (unsigned)(base[i] + (oh * c.OW + ow) * c.CO + co), lds + (wv + 4 * i) * 1024);
+          }
+        }
+      }
+    } else {
+      // piece 4 w + i = k-rows 16 w + 4 i .. + 3; lane l: k-row + (l >> 4), slot l & 15 holds row chunk slot ^ swz_t(k)
+      const int lane = threadIdx.x & 63;
+      const int kk0 = 16 * wv + (lane >> 4);
+      int t = 0, co = 0;
+      if (GATHER == 4) divmod(k0 + kk0 < kend ? k0 + kk0 : 0, c.CO, c.r_co, t, co);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kk = kk0 + 4 * i;
+        const int rc = (lane & 15) ^ swz_t(kk);
+        const int row = row0 + (rc << 3);
+        const bool ok = rc < ROWS / 8 && row < rows && k0 + kk < kend;
+        if (GATHER == 0) dma16(rs, ok, (unsigned)(k0 + kk) * uld + (unsigned)row, lds + (4 * wv + i) * 1024);
+        else dma16(rs, ok, (unsigned)co * uld + (unsigned)(t * c.CI + row), lds + (4 * wv + i) * 1024);   // GATHER 4
+        if (GATHER == 4) { co += 4; if (co >= c.CO) { co -= c.CO; ++t; } }
+      }
+    }
+  }
+
   // bf16(relu(fma(x, scale[c], shift[c]))) on the chunks of the tile in r[]; chunks without operand data stay zero
   __device__ __forceinline__ void transform(const GemmArgs& g) {
     const f32x4 s0 = *reinterpret_cast<const f32x4*>(g.tf_scale + tfc), s1 = *reinterpret_cast<const f32x4*>(g.tf_scale + tfc + 4);
@@ -482,7 +566,7 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 3) void gemm_bf16_kernel(GemmArgs
 
   // Lean variants (always at least one k-tile) start the accumulators with the first tile's first MFMA, whose
   // addend is then the constant zero: 16 * MI register clears fewer per wave.
-  constexpr bool kPeelZero = EPI != 0 && STAGES == 1;
+  constexpr bool kPeelZero = EPI != 0 && STAGES != 2;
   f32x4 acc[MI][4];
   if (!kPeelZero) {
 #pragma unroll
@@ -544,7 +628,37 @@ __global__ __launch_bounds__(kThreads, V ? 4 : 3) void gemm_bf16_kernel(GemmArgs
   using No = std::false_type;
 
   int t = next_tile(0);
-  if (STAGES == 2) {
+  if constexpr (STAGES == 3) {
+    // LDS-DMA, two buffers: the next tile lands in the other buffer while this one is read. One barrier per k-tile:
+    // behind it every wave's pieces of tile t are in LDS (each wave waited for its own) and nobody reads the buffer
+    // tile t + 1 is about to overwrite (it held tile t - 1).
+    if (t < nt) {
+      sa.dma(g, Ap, g.lda, g.M, m0, kbeg + t * BK, kend, tap, smem);
+      sb.dma(g, Bp, g.ldb, g.N, n0, kbeg + t * BK, kend, tap, smem + kTileBytes);
+    }
+    int cur = 0;
+    bool first = kPeelZero;
+    while (t < nt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const int tnext = next_tile(t + 1);
+      if (tnext < nt) {
+        char* nb = smem + (cur ^ 1) * kStage;
+        const int k0 = kbeg + tnext * BK;
+        sa.dma(g, Ap, g.lda, g.M, m0, k0, kend, tap, nb);
+        sb.dma(g, Bp, g.ldb, g.N, n0, k0, kend, tap, nb + kTileBytes);
+      }
+      if (kPeelZero && first) {
+        compute(smem + cur * kStage, Yes{});
+        first = false;
+      } else {
+        compute(smem + cur * kStage, No{});
+      }
+      cur ^= 1;
+      t = tnext;
+    }
+    __syncthreads();                       // the store phase stages through the operand buffers
+  } else if (STAGES == 2) {
     // two LDS buffers (64 KiB, 2 blocks per CU): the next tile is written while this one is read
     if (t < nt) {
       sa.load(g, Ap, g.lda, g.M, m0, kbeg + t * BK, kend, tap);
@@ -1090,6 +1204,37 @@ DTF_API void dtf_gemm_set_xcd_splits(int on) { g_xcd_splits = on != 0; }
 static int g_lean = 1;                   // lean store phase where it applies (measurement hook: 0 = never,
 DTF_API void dtf_gemm_set_lean(int on) { g_lean = on; }   // 1 = everywhere, 2 = plain products only)
 
+static int g_dma_min_tiles = 1 << 20;    // automatic choice of the LDS-DMA main loop: k-tiles per block from which it is
+                                         // taken (off by default: see gemm_dma_pays)
+DTF_API void dtf_gemm_set_dma_min_tiles(int n) { g_dma_min_tiles = n; }
+
+// Launches that have an LDS-DMA main loop (STAGES 3): the 128x128 tile; plain products in every layout, the
+// convolution forward and data gradient. The per-tap weight gradient's gathered x operand and the operand transform
+// have no DMA form.
+static bool gemm_dma_ok(int layout, int conv, int variant, const GemmArgs& g) {
+  if (variant != 0 || g.tf_scale) return false;
+  return conv == 0 || (conv == 1 && layout == 0) || (conv == 2 && layout == 1);
+}
+// ... and where it measured faster than the register-staged loop (tools/bench_gemm_dma.py): it holds two 32 KiB
+// buffers, so two blocks per CU instead of three, and its prefetch is one k-tile deep; that pays on long
+// contractions of MFMA-bound products (+14-18 % from 2048 deep: 838-948 TFLOP/s at 8192 x 4096 x 4096) and loses on
+// the short, memory-bound ones of the 1x1 convolutions. The [k][row] B image of the NN layout gains less: forward-type
+// products (NT, convolution forward) from g_dma_min_tiles k-tiles, the other layouts from twice as many. In the
+// ResNet-50 step a threshold of 32 changed nothing measurable (74.7 vs 74.4 ms: the 3x3 forward of 256 / 512
+// channels gains 5 %, and large dense products already run on the 256x256 kernel), so the automatic choice is off and
+// the loop is reached through dtf_gemm_set_stages(3) / dtf_gemm_set_dma_min_tiles.
+static bool gemm_dma_pays(int layout, int conv, int k_tiles) {
+  const int min_tiles = layout == 0 ? g_dma_min_tiles : 2 * g_dma_min_tiles;
+  (void)conv;
+  return k_tiles >= min_tiles;
+}
+
+template <int AT, int BT, int CV, int E>
+static void launch_dma(dim3 grid, size_t lds, hipStream_t stream, const GemmArgs& g) {
+  if constexpr (CV <= 2)
+    hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 3, 0, 0, E>), grid, dim3(kThreads), lds, stream, g);
+}
+
 static int g_stages = 0;                 // 0 = automatic
 constexpr int kSingleStageTiles = 1 << 20;   // in effect always: one buffer also measured faster on the long weight-gradient loops
 
@@ -1214,11 +1359,14 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   // (k-tiles per block <= kSingleStageTiles) are latency- and bandwidth-bound and run better with one
   // buffer and twice the resident blocks. g_stages overrides (1 or 2) for A/B measurements.
   const int k_tiles = kps / BK;
-  const int stages = g.tf_scale ? 1 : g_stages == 1 || g_stages == 2 ? g_stages : (k_tiles <= kSingleStageTiles ? 1 : 2);
+  // 3 = LDS-DMA with two buffers (dma_ok: the layouts that have a DMA form, see gemm_dma_ok)
+  const bool dma_ok = gemm_dma_ok(layout, conv, variant, g);
+  int stages = g.tf_scale ? 1 : g_stages == 1 || g_stages == 2 ? g_stages : (k_tiles <= kSingleStageTiles ? 1 : 2);
+  if (dma_ok && (g_stages == 3 || (g_stages == 0 && gemm_dma_pays(layout, conv, k_tiles)))) stages = 3;
   // LDS per stage: A image + B image (a row-contiguous B keeps 256-byte k-rows in either variant)
   const size_t b_tile = (layout == 0 && variant ? 64 : 128) * BK * 2;
   const size_t stage_bytes = kTileBytes + b_tile;
-  const size_t lds = (stages == 2 ? 2 : 1) * stage_bytes;
+  const size_t lds = (stages >= 2 ? 2 : 1) * stage_bytes;
   // the lean store-phase variant that matches the request exactly (0 = none does: the general kernel)
   int epi = 0;
   // (the 128x128 form of the stride-1 data gradient spills with the look-ahead of the lean store phase and measured
@@ -1226,7 +1374,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
   // classes run 1-4 filter taps deep and which carries no statistics, takes the plain lean form in both tiles.)
   const bool lean_conv = (conv == 0 && layout != 2) || (g_lean == 1 && conv == 1 && layout == 0) ||
                          (g_lean == 1 && conv == 2 && layout == 1);
-  if (g_lean && splits == 1 && !bias && act == 0 && !g.drop_thresh && !out_fp32 && !g.up2 && stages == 1 && lean_conv &&
+  if (g_lean && splits == 1 && !bias && act == 0 && !g.drop_thresh && !out_fp32 && !g.up2 && stages != 2 && lean_conv &&
       !g.tf_scale && batch == 1) {
     epi = 1 | (g.col_stats && g.stats_mode == 0 ? 2 : 0) | (g.Cin ? 4 : 0) | (g.col_stats && g.stats_mode == 1 ? 8 : 0);
     const bool have = conv == 1 ? (epi == 1 || epi == 3)
@@ -1237,11 +1385,13 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
 #define GEMM_LEAN(BT, CV, E)                                                                                   \
   do {                                                                                                         \
     if (variant) hipLaunchKernelGGL((gemm_bf16_kernel<0, BT, CV, 1, 1, 0, E>), grid, dim3(kThreads), lds, stream, g); \
+    else if (stages == 3) launch_dma<0, BT, CV, E>(grid, lds, stream, g);                                        \
     else if (CV != 2) hipLaunchKernelGGL((gemm_bf16_kernel<0, BT, CV == 2 ? 0 : CV, 1, 0, 0, E>), grid, dim3(kThreads), lds, stream, g); \
   } while (0)
 #define GEMM_LAUNCH(AT, BT, CV)                                                                              \
   do {                                                                                                       \
     if (variant) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 1, 1>), grid, dim3(kThreads), lds, stream, g); \
+    else if (stages == 3) launch_dma<AT, BT, CV, 0>(grid, lds, stream, g);                                     \
     else if (stages == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 2, 0>), grid, dim3(kThreads), lds, stream, g); \
     else hipLaunchKernelGGL((gemm_bf16_kernel<AT, BT, CV, 1, 0>), grid, dim3(kThreads), lds, stream, g);     \
   } while (0)
@@ -1268,6 +1418,7 @@ static int gemm_launch(int layout, const void* A, const void* B, void* C, const 
       case 64 + 3: GEMM_LEAN(0, 1, 3); break;
       case 128 + 16 + 1:
         if (variant) GEMM_LEAN(1, 2, 1);
+        else if (stages == 3) launch_dma<0, 1, 2, 1>(grid, lds, stream, g);
         else hipLaunchKernelGGL((gemm_bf16_kernel<0, 1, 2, 1, 0, 0, 1>), grid, dim3(kThreads), lds, stream, g);
         break;
       case 128 + 16 + 9: GEMM_LEAN(1, 2, 9); break;

@@ -52,6 +52,10 @@ def kernels() -> ctypes.CDLL:
         cap = os.environ.get("DTF_STREAM_BLOCKS")       # A/B switch: grid cap of the streaming kernels
         if cap:
             _kernels.dtf_set_stream_blocks(int(cap))
+        if os.environ.get("DTF_GEMM_STAGES"):           # A/B switch: main loop of the 128x128 GEMM (1, 2: LDS buffers of the
+            _kernels.dtf_gemm_set_stages(int(os.environ["DTF_GEMM_STAGES"]))   # register-staged loop; 3: LDS-DMA)
+        if os.environ.get("DTF_GEMM_DMA_MIN_TILES"):    # k-tiles per block from which the LDS-DMA loop is chosen
+            _kernels.dtf_gemm_set_dma_min_tiles(int(os.environ["DTF_GEMM_DMA_MIN_TILES"]))
         if os.environ.get("DTF_GEMM_XCD_SPLITS") == "0":  # A/B switch: split-K tiles dealt round-robin over the XCDs
             _kernels.dtf_gemm_set_xcd_splits(0)
         if os.environ.get("DTF_GEMM_LEAN"):             # A/B switch: 0 = general store phase everywhere,
