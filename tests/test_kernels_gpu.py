@@ -576,6 +576,45 @@ def test_max_pool_matches_torch(cfg):
 
 
 @pytest.mark.gpu
+def test_lds_dma_main_loop_matches_the_register_staged_one():
+    """The LDS-DMA main loop of the 128x128 kernel (dtf_gemm_set_stages(3)): every layout, ragged edges, and the
+    convolution gathers (padding and tile edges arrive as zeros written by out-of-range lanes)."""
+    from distributed_tensorflow_amd.ops import _lib, conv
+    from distributed_tensorflow_amd.ops import gemm as G
+    lib = _lib.kernels()
+    torch.manual_seed(21)
+    M, N, K = 1000, 264, 328                  # nothing a multiple of the tile
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    w_nt = (torch.randn(N, K, device=DEV) * 0.1).bfloat16()
+    w_nn = w_nt.t().contiguous()
+    gy = torch.randn(M, N, device=DEV).bfloat16()
+    x = torch.randn(3, 136, 13, 13, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(144, 136, 3, 3, device=DEV) * 0.05).bfloat16().contiguous(memory_format=torch.channels_last)
+
+    def run_all():
+        out = {}
+        out["nt"] = G.gemm_raw(G.NT, a, w_nt, torch.empty(M, N, device=DEV, dtype=torch.bfloat16), M, N, K, K, K, N)
+        out["nn"] = G.gemm_raw(G.NN, a, w_nn, torch.empty(M, N, device=DEV, dtype=torch.bfloat16), M, N, K, K, N, N)
+        out["tn"] = G.gemm_raw(G.TN, gy, a, torch.empty(N, K, device=DEV, dtype=torch.bfloat16), N, K, M, N, K, K,
+                               splits=1)
+        x1 = x.clone().requires_grad_(True)
+        y = conv.conv2d(x1, w, 1, 1)
+        y.backward(torch.ones_like(y))
+        out["conv"], out["conv_dx"] = y.detach(), x1.grad
+        return out
+    try:
+        lib.dtf_gemm_set_stages(1)
+        ref = run_all()
+        lib.dtf_gemm_set_stages(3)
+        got = run_all()
+    finally:
+        lib.dtf_gemm_set_stages(0)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k           # same products in the same order: bit-identical
+    assert torch.allclose(got["nt"].float(), a.float() @ w_nt.float().t(), atol=0.15, rtol=3e-2)
+
+
+@pytest.mark.gpu
 def test_stem_norm_pool_takes_the_statistics_of_the_first_convolution():
     """conv(7x7 / 2, 3 channels) -> norm + ReLU + max pool: the convolution's store phase reduces the norm's statistics;
     the result must match the path where the norm reduces them itself (and fp32 torch)."""
