@@ -74,6 +74,10 @@ def main() -> int:
         if not torch.cuda.is_available():
             print("bench.py needs a GPU (use --device cpu only for plumbing tests)", file=sys.stderr)
             return 2
+        # DTF_BENCH_SHARE_GPU=1 (rehearsals on a box with fewer GPUs than ranks; use with DTF_COMM=gloo, RCCL
+        # refuses two ranks on one device): ranks are dealt round-robin over the GPUs that exist
+        if os.environ.get("DTF_BENCH_SHARE_GPU") == "1":
+            local_rank %= max(1, torch.cuda.device_count())
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)
     else:
