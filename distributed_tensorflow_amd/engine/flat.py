@@ -170,7 +170,11 @@ class BucketPlanner:
     """Cuts the flat index space into contiguous buckets of whole slots.
 
     ``cap_bytes`` bounds a bucket; ``first_cap_bytes`` lets bucket 0 be smaller so
-    the first collective starts early in backward. Slots are padded to
+    the first collective starts early in backward; ``last_cap_bytes`` cuts a small
+    bucket off the end: the last bucket becomes ready only when backward is over, so
+    its collective is the one nothing can hide, and everything before the cut (in
+    ResNet-50 the parameter-heavy late stages, whose gradients exist early) then
+    travels while the early layers' backward still runs. Slots are padded to
     ``ALIGN * shard_ways`` elements by :class:`FlatParams`, so every bucket splits
     evenly into ``shard_ways`` aligned shards for reduce-scatter / all-gather.
 
@@ -180,7 +184,8 @@ class BucketPlanner:
     launch latency, dominates.
     """
 
-    def __init__(self, flat: FlatParams, cap_bytes: int = 48 << 20, first_cap_bytes: int | None = None):
+    def __init__(self, flat: FlatParams, cap_bytes: int = 48 << 20, first_cap_bytes: int | None = None,
+                 last_cap_bytes: int | None = None):
         self.flat = flat
         self.shard_ways = flat.shard_ways
         esize = flat.grad.element_size()
@@ -195,6 +200,13 @@ class BucketPlanner:
                 buckets.append(Bucket(len(buckets), start, s.offset, tuple(cur)))
                 start, cur, limit = s.offset, [], cap
             cur.append(s)
+        if last_cap_bytes and len(cur) > 1 and flat.total - start > last_cap_bytes // esize:
+            # the longest run of trailing slots that fits the small cap (at least one slot) becomes its own bucket
+            cut = len(cur) - 1
+            while cut > 1 and flat.total - cur[cut - 1].offset <= last_cap_bytes // esize:
+                cut -= 1
+            buckets.append(Bucket(len(buckets), start, cur[cut].offset, tuple(cur[:cut])))
+            start, cur = cur[cut].offset, cur[cut:]
         buckets.append(Bucket(len(buckets), start, flat.total, tuple(cur)))
         self.buckets = buckets
         self.slot_bucket = {id(s.param): b for b in buckets for s in b.slots}

@@ -37,6 +37,7 @@ class TrainConfig:
     grad_dtype: torch.dtype = torch.float32
     bucket_bytes: int = 48 << 20
     first_bucket_bytes: int | None = 8 << 20
+    last_bucket_bytes: int | None = 4 << 20   # the last bucket's collective is exposed: keep it small
     shard_ways: int = 1
     seed: int = 0
     graph: bool = False                   # capture the whole train step into a hipGraph (GPU, static shapes)
@@ -62,7 +63,8 @@ class Replica:
         if self.cfg.param_dtype is not None and self.cfg.param_dtype != torch.float32:
             _cast_params(self.model, self.cfg.param_dtype, self.cfg.keep_fp32)
         self.flat = FlatParams.from_module(self.model, grad_dtype=self.cfg.grad_dtype, shard_ways=self.cfg.shard_ways)
-        self.planner = BucketPlanner(self.flat, self.cfg.bucket_bytes, self.cfg.first_bucket_bytes)
+        self.planner = BucketPlanner(self.flat, self.cfg.bucket_bytes, self.cfg.first_bucket_bytes,
+                                     self.cfg.last_bucket_bytes)
         self.reducer = GradReducer(self.flat, self.planner)
         self.reducer.attach()
         self.step_count = 0

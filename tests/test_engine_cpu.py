@@ -86,6 +86,24 @@ def test_bucket_planner_partitions_the_arena(ways):
     assert len(pl.buckets) > 2
 
 
+def test_bucket_planner_cuts_a_small_last_bucket():
+    m = mnist_cnn()
+    f = FlatParams.from_module(m)
+    whole = BucketPlanner(f, cap_bytes=1 << 30)
+    assert len(whole.buckets) == 1
+    esize = f.grad.element_size()
+    tail = (f.total - f.slots[-2].offset) * esize           # the last two slots
+    pl = BucketPlanner(f, cap_bytes=1 << 30, last_cap_bytes=tail)
+    assert len(pl.buckets) == 2 and len(pl.buckets[1].slots) == 2
+    assert pl.buckets[0].end == pl.buckets[1].start == f.slots[-2].offset and pl.buckets[1].end == f.total
+    assert sum(len(b.slots) for b in pl.buckets) == len(f.slots)
+    # a cap smaller than the last slot still leaves that slot a bucket of its own
+    pl = BucketPlanner(f, cap_bytes=1 << 30, last_cap_bytes=1)
+    assert len(pl.buckets) == 2 and len(pl.buckets[1].slots) == 1
+    # and a last bucket that already fits is left alone
+    assert len(BucketPlanner(f, cap_bytes=1 << 30, last_cap_bytes=1 << 30).buckets) == 1
+
+
 def test_adam_keras_formula_matches_handwritten():
     torch.manual_seed(0)
     m = reference_mlp()
