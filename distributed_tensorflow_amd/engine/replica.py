@@ -88,7 +88,8 @@ class Replica:
     def forward_backward(self, x, y, on_bucket_ready=None, grad_scale: float = 1.0) -> torch.Tensor:
         """Forward + backward; returns the detached scalar loss (mean over the batch, for logging).
         ``grad_scale`` is folded into the bucket packing kernel (e.g. 1/world)."""
-        self.model.train(self.cfg.training)
+        if self.model.training != self.cfg.training:   # walks every module: only when the mode actually changes
+            self.model.train(self.cfg.training)
         self.reducer.on_ready = on_bucket_ready
         self.reducer.grad_scale = grad_scale
         self.reducer.begin_step()

@@ -108,7 +108,7 @@ _workspaces: dict[tuple, torch.Tensor] = {}
 def _workspace(device, numel: int) -> torch.Tensor:
     # one workspace per stream: launches on one stream are ordered, launches on different streams
     # (parameter-server service threads) must not share scratch memory
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = (device.type, device.index, _lib.stream_ptr(device).value if device.type == "cuda" else 0)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < numel:
         ws = torch.empty(max(numel, 1 << 22), dtype=torch.float32, device=device)

@@ -1,7 +1,8 @@
 """Times forward / data-gradient / weight-gradient of single convolutions, own kernel vs vendor library.
 
-usage: python tools/bench_conv.py [batch] [--library]    (ResNet-50 strided and 3x3 shapes, batch 256 by default;
-the framework's own kernels, plus the vendor library's for comparison with --library; TF = TFLOP/s)
+usage: python tools/bench_conv.py [batch] [--library] [--3x3]   (ResNet-50 strided and 3x3 shapes, batch 256 by
+default; the framework's own kernels, plus the vendor library's for comparison with --library; --3x3: only the
+stride-1 3x3 layers from 128 channels up, e.g. under a counter run; TF = TFLOP/s)
 """
 import os
 import sys
@@ -36,6 +37,8 @@ def main():
         (256, 512, 7, 7, 512, 3, 1, 1),
     ]
     shapes = [(nb,) + t[1:] for t in shapes]
+    if "--3x3" in sys.argv:
+        shapes = [t for t in shapes if t[5] == 3 and t[6] == 1 and t[1] >= 128]
     lines = [f"{'shape (N, CI, H, W, CO, k, stride, pad)':44s} {'backend':8s} {'fwd_us':>8s} {'dgrad_us':>9s} {'wgrad_us':>9s}"
              f" {'fwd_TF':>7s} {'dgrad_TF':>8s} {'wgrad_TF':>8s}"]
     print(lines[0])

@@ -42,6 +42,45 @@ def main():
         st.train_step(x, y)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps * 1e3
+    # backward runs on the autograd engine's own thread, which cProfile does not see: time every custom Function's
+    # backward with a wrapper instead (host time only; kernels are asynchronous)
+    import collections
+    from distributed_tensorflow_amd.ops import conv as _c, norm as _n, dense as _d, pool as _p, softmax_ce as _s
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    inner = cProfile.Profile() if os.environ.get("PROFILE_BACKWARD") == "1" else None   # function-level view of backward
+    patched = []
+    for mod in (_c, _n, _d, _p, _s):
+        for nm in dir(mod):
+            cls = getattr(mod, nm)
+            if isinstance(cls, type) and issubclass(cls, torch.autograd.Function) and cls is not torch.autograd.Function:
+                orig = cls.backward
+
+                def wrap(orig=orig, key=f"{mod.__name__.rsplit('.', 1)[-1]}.{nm}"):
+                    def timed(*a, **k):
+                        t = time.perf_counter()
+                        if inner is not None:
+                            inner.enable()
+                            r = orig(*a, **k)
+                            inner.disable()
+                        else:
+                            r = orig(*a, **k)
+                        e = acc[key]
+                        e[0] += 1
+                        e[1] += time.perf_counter() - t
+                        return r
+                    return staticmethod(timed)
+                cls.backward = wrap()
+                patched.append((cls, orig))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.train_step(x, y)
+    torch.cuda.synchronize()
+    wall_b = (time.perf_counter() - t0) / steps * 1e3
+    for cls, orig in patched:
+        cls.backward = staticmethod(orig)
+    bw_lines = [f"backward host time per step (wrapped run: {wall_b:.3f} ms per step)\n"]
+    for key, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        bw_lines.append(f"  {key:40s} {n / steps:6.1f} calls  {t / steps * 1e3:7.3f} ms  ({t / max(n, 1) * 1e6:5.1f} us each)\n")
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(steps):
@@ -50,6 +89,10 @@ def main():
     pr.disable()
     out = io.StringIO()
     out.write(f"{name}: {wall:.3f} ms per eager step (unprofiled), {steps} profiled steps below\n")
+    out.write("".join(bw_lines))
+    if inner is not None:
+        out.write("inside the backward functions (profiled on the autograd thread):\n")
+        pstats.Stats(inner, stream=out).sort_stats("tottime").print_stats(30)
     pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(35)
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/host_profile_{name}.txt", "w") as f:
