@@ -53,6 +53,10 @@ def main() -> int:
                          "graph[:degree] | sync | async (default: keras for resnet50, custom:ring for bert)")
     ap.add_argument("--grad-dtype", default="bf16", choices=["bf16", "fp32"], help="dtype the gradients are exchanged in")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph")
+    ap.add_argument("--input", default="device", choices=["device", "host"],
+                    help="device: one synthetic batch resident on the GPU (tf_cnn_benchmarks-style synthetic data); host: "
+                         "uint8 images in host memory, gathered per step by the native loader threads, uploaded on a copy "
+                         "stream one step ahead and normalised on the GPU (ResNet-50 only)")
     ap.add_argument("--phase-steps", type=int, default=3, help="untimed steps after the timed loop that measure per-phase device time (0 = skip)")
     a = ap.parse_args()
 
@@ -129,6 +133,16 @@ def main() -> int:
 
     st.cfg.graph = bool(a.graph and dev.type == "cuda")
     step = st.step_callable()
+    feed = None
+    if a.input == "host":
+        if a.model != "resnet50" or st.cfg.graph:
+            print("--input host feeds the eager ResNet-50 step only", file=sys.stderr)
+            return 2
+        feed = bench_lib.HostInputPipeline(batch, dev, size=a.image, seed=rank)
+        train = step
+
+        def step(_x, _y):      # noqa: F811 - every step trains on the batch the pipeline delivers
+            return train(*feed.next())
     # untimed priming before the counted warm-up steps: communicator set-up and (with --graph) the eager steps and
     # the capture all happen here, whatever --warmup is
     for _ in range(5 if st.cfg.graph else 2):
@@ -161,6 +175,8 @@ def main() -> int:
             phase_ms = {k: round(v, 3) for k, v in pt.report().items()}
         wait = sum(v for k, v in phase_ms.items() if k in ("grad_sync_wait", "push_wait", "pull", "push_pull", "gossip"))
         exposed = round(wait / step_ms, 4) if step_ms > 0 else None
+    if feed is not None:
+        feed.close()
     st.finalize()
     agree = None
     if st.replicas_agree or strategy.startswith(("graph", "async")):
@@ -181,6 +197,7 @@ def main() -> int:
             "metric": metric, "value": round(value, 2), "unit": unit,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "input": "one GPU-resident batch" if feed is None else "host uint8 pool -> loader threads -> pinned -> copy stream",
             "config": {**cfg_model, "global_batch": batch * world, "per_gpu_batch": batch,
                        "parallelism": f"dp{world}", "strategy": strategy, "grad_dtype": a.grad_dtype,
                        "conv1x1": conv.get_conv1x1_backend(), "convkxk": conv.get_convkxk_backend(),

@@ -44,6 +44,40 @@ def test_bench_single_process_cpu_plumbing():
     _check(lines[0], 1)
 
 
+def test_bench_host_input_pipeline_cpu_plumbing():
+    """--input host: every step trains on a batch that the native loader gathered from the host pool."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--device", "cpu", "--batch", "2", "--image", "32",
+                        "--steps", "2", "--warmup", "1", "--input", "host", "--phase-steps", "0"], env=ENV,
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["input"].startswith("host") and r["value"] > 0 and r["final_loss"] == r["final_loss"]
+
+
+def test_host_input_pipeline_delivers_the_pool_rows():
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, ROOT)
+    from distributed_tensorflow_amd.bench_lib import HostInputPipeline
+    feed = HostInputPipeline(4, "cpu", size=8, classes=10, pool=16, seed=3)
+    seen = []
+    for _ in range(5):
+        x, y = feed.next()
+        assert x.shape == (4, 8, 8, 3) and x.dtype == torch.bfloat16 and y.shape == (4,)
+        # every delivered image is a row of the pool, normalised, with that row's label
+        raw = (x.float() * 64.0 + 127.5).round().clamp(0, 255).to(torch.uint8).numpy()
+        for i in range(4):
+            match = [j for j in range(16) if int(feed._y[j]) == int(y[i])
+                     and np.abs(raw[i].astype(int) - feed._x[j].astype(int)).max() <= 1]
+            assert match, "delivered image is not a pool row"
+        seen.append(y.clone())
+    assert any(not torch.equal(seen[0], s) for s in seen[1:])       # batches differ from step to step
+    feed.close()
+
+
 @pytest.mark.slow
 def test_bench_two_ranks_under_torchrun_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
