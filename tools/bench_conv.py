@@ -38,7 +38,7 @@ def main():
     ]
     shapes = [(nb,) + t[1:] for t in shapes]
     if "--3x3" in sys.argv:
-        shapes = [t for t in shapes if t[5] == 3 and t[6] == 1 and t[1] >= 128]
+        shapes = [t for t in shapes if t[5] == 3 and t[6] == 1 and t[1] >= (64 if '--64' in sys.argv else 128)]
     lines = [f"{'shape (N, CI, H, W, CO, k, stride, pad)':44s} {'backend':8s} {'fwd_us':>8s} {'dgrad_us':>9s} {'wgrad_us':>9s}"
              f" {'fwd_TF':>7s} {'dgrad_TF':>8s} {'wgrad_TF':>8s}"]
     print(lines[0])
