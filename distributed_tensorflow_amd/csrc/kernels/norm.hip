@@ -398,6 +398,114 @@ __global__ __launch_bounds__(kBlock) void bn_fold_partials_kernel(const float* _
   out[(long long)blockIdx.x * width + e] = (a + b) + (c + d);
 }
 
+// Fold + finalize in ONE launch, for statistics that arrive as more than kFoldAbove partial rows (the per-tile rows
+// a convolution's store phase wrote: 25088 of them behind a 56x56 layer at batch 1024). Block (g, j) sums rows
+// [g * per, (g + 1) * per) of 32 channels (both statistics: 64 columns, one per lane of a wave, 16 waves = 16 row
+// lanes) and leaves one row in `ws`; the block that arrives last at the channel group's counter sums those rows in a
+// fixed order and finishes the statistics, so no float atomics and bitwise reproducible results. The counter is
+// back at zero when the kernel ends. MODE 0: forward (mean, 1/std, scale, shift, running statistics), MODE 1:
+// backward (dgamma, dbeta, dx coefficients; the partials hold sum dy' * (x - mean)).
+constexpr int kRfThreads = 1024, kRfCh = 32, kRfLanes = kRfThreads / (2 * kRfCh), kRfGroups = 64;
+
+struct BnFin {
+  const float* gamma; const float* beta; float* run_mean; float* run_var;      // forward
+  float* mean; float* invstd; float* scale; float* shift; float eps, momentum;
+  float* dgamma; float* dbeta; float* cA; float* cK; float* c0;                // backward (reads mean, invstd)
+  long long M; int C;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kRfThreads) void bn_reduce_finalize_kernel(const float* __restrict__ part, int n_rows,
+                                                                        int per, float* __restrict__ ws,
+                                                                        unsigned* __restrict__ counters, BnFin f) {
+  __shared__ float red[kRfLanes][2 * kRfCh];
+  __shared__ unsigned is_last;
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+  const int ch = j * kRfCh + (col & 31);
+  const long long width = 2LL * f.C;
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  if (ch < f.C) {
+    const int r1 = min(n_rows, (g + 1) * per);
+    int r = g * per + rl;
+    const float* q = part + (long long)r * width + (col >> 5) * f.C + ch;
+    const long long st = kRfLanes * width;
+    for (; r + 3 * kRfLanes < r1; r += 4 * kRfLanes, q += 4 * st) { a += q[0]; b += q[st]; c += q[2 * st]; d += q[3 * st]; }
+    for (; r < r1; r += kRfLanes, q += st) a += q[0];
+  }
+  red[rl][col] = (a + b) + (c + d);
+  __syncthreads();
+  float* mine = ws + ((long long)j * G + g) * 64;
+  if (rl == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kRfLanes; ++k) s += red[k][col];
+    // Device-scope stores go through to the level all XCDs share, and the wait below returns once they are
+    // acknowledged there; the counter (device scope as well) moves only after that. A release fence instead would
+    // write back the whole L2 of this XCD, dirty with the activation the producer has just stored: measured 275 us
+    // per launch against 10.
+    __hip_atomic_store(mine + col, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    is_last = __hip_atomic_fetch_add(counters + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(G - 1);
+  __syncthreads();
+  if (!is_last) return;
+  // G <= kRfGroups rows, kRfGroups / kRfLanes per row lane: all loads in flight before the first add
+  float v[kRfGroups / kRfLanes];
+#pragma unroll
+  for (int i = 0; i < kRfGroups / kRfLanes; ++i) {
+    const int k = rl + i * kRfLanes;
+    v[i] = __hip_atomic_load(ws + ((long long)j * G + min(k, G - 1)) * 64 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k >= G) v[i] = 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kRfGroups / kRfLanes; ++i) s += v[i];
+  red[rl][col] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(counters + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int cc = j * kRfCh + threadIdx.x;
+  if (threadIdx.x >= kRfCh || cc >= f.C) return;
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < kRfLanes; ++k) { s0 += red[k][threadIdx.x]; s1 += red[k][kRfCh + threadIdx.x]; }
+  const float inv_m = 1.f / (float)f.M;
+  if (MODE == 0) {
+    const float mu = s0 * inv_m;
+    const float var = fmaxf(s1 * inv_m - mu * mu, 0.f);
+    const float is = rsqrtf(var + f.eps);
+    f.mean[cc] = mu; f.invstd[cc] = is;
+    const float sc = f.gamma[cc] * is;
+    f.scale[cc] = sc; f.shift[cc] = f.beta[cc] - mu * sc;
+    if (f.run_mean) {
+      const float unbiased = f.M > 1 ? var * (float)f.M / (float)(f.M - 1) : var;
+      f.run_mean[cc] = (1.f - f.momentum) * f.run_mean[cc] + f.momentum * mu;
+      f.run_var[cc] = (1.f - f.momentum) * f.run_var[cc] + f.momentum * unbiased;
+    }
+  } else {
+    const float is = f.invstd[cc];
+    s1 *= is;
+    f.dbeta[cc] = s0; f.dgamma[cc] = s1;
+    const float sc = f.gamma[cc] * is;
+    const float k = sc * s1 * inv_m * is;
+    f.cA[cc] = sc; f.cK[cc] = -k; f.c0[cc] = f.mean[cc] * k - sc * s0 * inv_m;
+  }
+}
+
+template <int MODE>
+static void launch_reduce_finalize(const float* part, int n_rows, float* ws, unsigned* counters, const BnFin& f,
+                                   hipStream_t stream) {
+  const int per = (n_rows + kRfGroups - 1) / kRfGroups;
+  const int G = (n_rows + per - 1) / per;
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel<MODE>, dim3(G, (f.C + kRfCh - 1) / kRfCh), dim3(kRfThreads), 0, stream,
+                     part, n_rows, per, ws, counters, f);
+}
+
+// counters a launch of the fused reduction needs (one per 32 channels), all zero before and after
+DTF_API int dtf_bn_reduce_counters(int C) { return (C + kRfCh - 1) / kRfCh; }
+
 constexpr int kFoldRows = 256;            // rows a fold leaves
 constexpr int kFoldAbove = kBnMaxPartials; // the finalize kernels take up to this many rows directly
 
@@ -407,11 +515,20 @@ constexpr int kFoldAbove = kBnMaxPartials; // the finalize kernels take up to th
 DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                    float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
                                    float* shift, const float* col_stats, int n_rows, float* workspace, void* mask_out,
-                                   long long M, int C, float eps, float momentum, int relu, hipStream_t stream) {
+                                   long long M, int C, float eps, float momentum, int relu, void* counters,
+                                   hipStream_t stream) {
   if (M <= 0 || C <= 0) return 0;
   if (C % 8 || !col_stats || n_rows < 1) return -1;
   const float* part = col_stats;
   int np = n_rows;
+  if (n_rows > kFoldAbove && counters) {
+    BnFin f = {};
+    f.gamma = gamma; f.beta = beta; f.run_mean = run_mean; f.run_var = run_var; f.mean = mean; f.invstd = invstd;
+    f.scale = scale; f.shift = shift; f.eps = eps; f.momentum = momentum; f.M = M; f.C = C;
+    launch_reduce_finalize<0>(col_stats, n_rows, workspace, (unsigned*)counters, f, stream);
+    if (y) launch_apply_fwd(x, res, scale, shift, y, mask_out, M, C, relu, stream);
+    return (int)hipGetLastError();
+  }
   if (n_rows > kFoldAbove) {
     const int per = (n_rows + kFoldRows - 1) / kFoldRows;
     np = (n_rows + per - 1) / per;
@@ -464,11 +581,19 @@ DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float
 DTF_API int dtf_bn_bwd_stats(const void* x, const void* dy, const void* y, const float* gamma, const float* mean,
                              const float* invstd, const float* scale, const float* shift, void* dx, void* dres,
                              float* dgamma, float* dbeta, float* coef, const float* col_stats, int n_rows,
-                             float* workspace, long long M, int C, int relu, hipStream_t stream) {
+                             float* workspace, long long M, int C, int relu, void* counters, hipStream_t stream) {
   if (M <= 0 || C <= 0) return 0;
   if (C % 8 || !col_stats || n_rows < 1) return -1;
   const float* part = col_stats;
   int np = n_rows;
+  if (n_rows > kFoldAbove && counters) {
+    BnFin f = {};
+    f.gamma = gamma; f.mean = const_cast<float*>(mean); f.invstd = const_cast<float*>(invstd); f.dgamma = dgamma;
+    f.dbeta = dbeta; f.cA = coef; f.cK = coef + C; f.c0 = coef + 2 * C; f.M = M; f.C = C;
+    launch_reduce_finalize<1>(col_stats, n_rows, workspace, (unsigned*)counters, f, stream);
+    launch_apply_bwd(x, dy, y, coef, scale, shift, dx, dres, M, C, relu, stream);
+    return (int)hipGetLastError();
+  }
   if (n_rows > kFoldAbove) {
     const int per = (n_rows + kFoldRows - 1) / kFoldRows;
     np = (n_rows + per - 1) / per;

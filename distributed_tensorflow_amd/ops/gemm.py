@@ -167,13 +167,34 @@ def _launch(layout: int, A, B, M, N, K, lda, ldb, bias, activation, out_dtype, s
         if bias.numel() != N or not bias.is_contiguous():
             raise ValueError("bias must be a contiguous [N] vector")
         bias_dtype = _lib.dtype_code(bias.dtype)
+    log = launch_log
+    if log is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     rc = _lib.kernels().dtf_gemm_bf16_ex(layout, _lib.ptr(A), _lib.ptr(B), _lib.ptr(out), _lib.ptr(bias), M, N, K,
                                          ctypes.c_longlong(lda), ctypes.c_longlong(ldb), ctypes.c_longlong(ldc),
                                          bias_dtype, _ACT[activation], 1 if out.dtype == torch.float32 else 0,
                                          splits, _lib.ptr(ws), ctypes.byref(extra) if extra is not None else None,
                                          _lib.stream_ptr(dev))
     _lib.check(rc, "gemm_bf16")
+    if log is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        e = extra
+        log.append((dict(layout=layout, M=M, N=N, K=K, batch=batch, splits=splits, fp32_out=out.dtype == torch.float32,
+                         conv=e.conv if e else 0, H=e.H if e else 0, W=e.W if e else 0, OH=e.OH if e else 0,
+                         OW=e.OW if e else 0, S=e.S if e else 0, KH=e.KH if e else 0, KW=e.KW if e else 0,
+                         CI=e.CI if e else 0, CO=e.CO if e else 0, NB=e.NB if e else 0, add=bool(e and e.Cin),
+                         add_mask=bool(e and e.cin_mask), stats=bool(e and e.col_stats),
+                         bn_grad=bool(e and e.stats_mode), bn_mask=bool(e and e.bn_mask), in_bn=bool(e and e.tf_scale),
+                         tile=e.tile if e else 0, up2=e.up2 if e else 0, bias=bias is not None,
+                         act=activation), ev0, ev1))
     return out
+
+
+# tools/roofline_step.py sets this to a list: every launch of the 128-wide kernel family then appends
+# (description, start event, end event) on the current stream (None: no logging, no cost)
+launch_log: list | None = None
 
 
 _big_tile = os.environ.get("DTF_GEMM256", "1") == "1"

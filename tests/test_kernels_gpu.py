@@ -995,6 +995,62 @@ def test_norm_backward_sums_from_the_consuming_convolution(block):
 
 
 @pytest.mark.gpu
+def test_fused_fold_and_finalize_matches_the_separate_kernels():
+    """More than 1024 partial rows (M / 128 with M = 48 * 56 * 56): the single-launch fold + finalize (last block
+    per channel group finishes the statistics) against the separate fold and finalize kernels, for the forward
+    statistics handed over by the producing convolution and the backward sums handed over by the consuming one."""
+    from distributed_tensorflow_amd.models import resnet as R
+    from distributed_tensorflow_amd.ops import norm
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(R.Bottleneck(64, 16, 1), R.Bottleneck(64, 16, 1)).to(DEV)
+    for m in net.modules():
+        if isinstance(m, R.Conv):
+            m.weight.data = m.weight.data.bfloat16().contiguous(memory_format=torch.channels_last)
+        if isinstance(m, R.BNAct):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+    net.train()
+    x = torch.randn(48, 64, 56, 56, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    assert x.shape[0] * 56 * 56 // 128 > 1024
+    wts = torch.rand(48 * 64 * 56 * 56, device=DEV) + 0.5
+    res = {}
+    saved = norm._fused_reduce
+    try:
+        for fused in (False, True):
+            norm._fused_reduce = fused
+            for p in net.parameters():
+                p.grad = None
+            for m in net.modules():
+                if isinstance(m, R.BNAct):
+                    m.running_mean.zero_()
+                    m.running_var.fill_(1.0)
+            xi = x.clone().requires_grad_(True)
+            out = net(xi)
+            (out.float() * wts.reshape(out.shape)).sum().backward()
+            torch.cuda.synchronize()
+            r = {n: p.grad.float().clone() for n, p in net.named_parameters()}
+            r["input"], r["out"] = xi.grad.float().clone(), out.float().clone()
+            for n, b in net.named_buffers():
+                if b.is_floating_point():
+                    r["buf." + n] = b.float().clone()
+            res[fused] = r
+    finally:
+        norm._fused_reduce = saved
+    assert norm._counters           # the fused kernel did run; its ring of counters is back at zero after every launch
+    for buf, _ in norm._counters.values():
+        assert int(buf.abs().sum()) == 0
+    for n, ref in res[False].items():
+        got = res[True][n]
+        err = float((got - ref).norm() / (ref.norm() + 1e-12))
+        # the same sums in another order: the statistics agree to fp32 rounding, parameter gradients (long sums)
+        # closely; the input gradient has passed six norms' backward passes, each rounding to bf16, where a last-bit
+        # change of a coefficient flips roundings (bf16 epsilon is 0.8 %)
+        tol = 1e-5 if n.startswith("buf.") else 2e-2 if n in ("input", "out") else 5e-3
+        assert err < tol, (n, err)
+    assert torch.allclose(res[True]["out"], res[False]["out"], atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.gpu
 def test_masked_residual_gradient_hand_over_and_its_guards():
     """norm-add-ReLU with a fork alias as residual: the branch gradient travels unmasked plus mask bits and the
     fork's data-gradient epilogue applies them; a second consumer of the alias must fail loudly."""

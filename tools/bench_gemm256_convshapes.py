@@ -1,7 +1,8 @@
 """Upper bound for a gathered-operand form of the 256x256 LDS-DMA kernel: the plain products with the dimensions of
 the 3x3 convolutions of ResNet-50's 256- and 512-channel stages at batch 1024 (im2col already materialised, so the
 operand is read 9 times from memory instead of from the cache), on the 256x256 kernel, the 128x128 kernel and the
-vendor library.  usage: python tools/bench_gemm256_convshapes.py"""
+vendor library.  usage: python tools/bench_gemm256_convshapes.py [MxNxK ...]   (default: the three 3x3 shapes; the 1x1
+products of the 256- to 2048-channel stages are e.g. 200704x1024x256 200704x256x1024 50176x2048x512 50176x512x2048)"""
 import os
 import sys
 
@@ -13,7 +14,9 @@ from tools.bench_kernels import DEV, timeit  # noqa: E402
 
 
 def main():
-    for (M, N, K) in [(200704, 256, 2304), (50176, 512, 4608), (802816, 128, 1152)]:
+    shapes = [tuple(int(v) for v in s.split("x")) for s in sys.argv[1:]] or [(200704, 256, 2304), (50176, 512, 4608),
+                                                                            (802816, 128, 1152)]
+    for (M, N, K) in shapes:
         a = torch.randn(M, K, device=DEV).bfloat16()
         b = torch.randn(N, K, device=DEV).bfloat16()
         bt = b.t().contiguous()
