@@ -40,7 +40,8 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=None,
                     help="per-GPU batch (weak scaling: fixed per GPU); default 1024 images (ResNet-50: 4 %% above 512\n"
-                         "on one MI355X, the per-layer reduction kernels are amortised over more work) / 64 sequences")
+                         "on one MI355X, the per-layer reduction kernels are amortised over more work) / 128 sequences (10 %% above 64:\n"
+                         "the 768-wide products then fill whole rounds of 256 x 256 tiles)")
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--bucket-mb", type=int, default=None, help="gradient bucket size (default 48 MiB)")
@@ -112,7 +113,7 @@ def main() -> int:
     else:
         from distributed_tensorflow_amd.models.bert import synthetic_mlm_batch
         strategy = a.strategy or "custom:ring"
-        batch = a.batch or 64
+        batch = a.batch or 128
         size = "base" if a.model == "bert" else "tiny"
         seq = a.seq_len if size == "base" else min(a.seq_len, 64)
         st = bench_lib.make_bert_strategy(comm, size, seq, bucket_mb=bucket_mb, grad_dtype=gdt, strategy=strategy)
