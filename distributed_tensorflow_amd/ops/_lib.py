@@ -52,6 +52,8 @@ def kernels() -> ctypes.CDLL:
         cap = os.environ.get("DTF_STREAM_BLOCKS")       # A/B switch: grid cap of the streaming kernels
         if cap:
             _kernels.dtf_set_stream_blocks(int(cap))
+        if os.environ.get("DTF_LN_BWD_BLOCKS"):         # A/B switch: block cap of the LayerNorm backward pass
+            _kernels.dtf_ln_set_bwd_blocks(int(os.environ["DTF_LN_BWD_BLOCKS"]))
         if os.environ.get("DTF_GEMM_STAGES"):           # A/B switch: main loop of the 128x128 GEMM (1, 2: LDS buffers of the
             _kernels.dtf_gemm_set_stages(int(os.environ["DTF_GEMM_STAGES"]))   # register-staged loop; 3: LDS-DMA)
         if os.environ.get("DTF_GEMM_DMA_MIN_TILES"):    # k-tiles per block from which the LDS-DMA loop is chosen
