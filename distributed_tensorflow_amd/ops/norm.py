@@ -88,7 +88,10 @@ class ForkToken:
     norm-add-ReLU, the norm's backward does not write the masked gradient of the residual branch: it hands the
     incoming gradient itself to the branch and leaves the ReLU mask here (``masked_grad`` = that gradient, its
     version counter, mask bytes); the fork's backward, which accumulates the branch gradient in its data-gradient GEMM
-    epilogue anyway, applies the mask there. One pass over the widest activations of the network is saved."""
+    epilogue anyway, applies the mask there. One pass over the widest activations of the network is saved.
+    The output of a plain batch norm (no ReLU, no residual: the norm of a down-sampling branch) carries a token too:
+    its own backward reads the gradient together with the mask bits (the kernels' ``relu == 3`` form) instead of a
+    masked copy."""
     __slots__ = ("masked_grad",)
 
     def __init__(self):
@@ -154,9 +157,11 @@ class _ApplyFn(torch.autograd.Function):
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, relu, residual, partials=None, request=None,
-                defer=False):
+                defer=False, out_token=None):
         """``defer``: finish the statistics only and return an alias of ``x`` (see :class:`DeferredNorm`); needs
-        ``partials`` and no residual."""
+        ``partials`` and no residual. ``out_token``: the :class:`ForkToken` of this norm's output (plain norms
+        only)."""
+        ctx.out_token = out_token
         N, C, H, W = x.shape
         M = N * H * W
         dev = x.device
@@ -208,6 +213,22 @@ class _BNActFn(torch.autograd.Function):
         N, C, H, W = x.shape
         M = N * H * W
         dev = x.device
+        relu_code = ctx.relu
+        tok = ctx.out_token
+        if tok is not None and tok.masked_grad is not None:
+            # the norm-add-ReLU that took this norm's output as its residual handed its incoming gradient over
+            # unmasked, with the mask bits: it must arrive here as that very tensor, untouched
+            handed, version, mask = tok.masked_grad
+            tok.masked_grad = None
+            if (dy.data_ptr() != handed.data_ptr() or dy._version != version or dy.shape != handed.shape):
+                raise RuntimeError("batch_norm_act: the output of a plain batch norm fed a norm-add-ReLU residual AND "
+                                   "another consumer; the masked gradient hand-over needs the residual to be its only "
+                                   "use (ops.conv.set_bn_stats(False) disables the hand-over)")
+            if dy.is_contiguous(memory_format=torch.channels_last) and dy.dtype == torch.bfloat16 and dy.shape == x.shape:
+                relu_code, y = 3, mask
+            else:
+                from .conv import _apply_mask_bits
+                dy = _apply_mask_bits(dy, mask)
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
@@ -232,12 +253,12 @@ class _BNActFn(torch.autograd.Function):
                                       _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(dx),
                                       _lib.ptr(dres), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(coef),
                                       _lib.ptr(part), int(part.shape[0]), _lib.ptr(ws), ctypes.c_longlong(M), C,
-                                      int(ctx.relu), _reduce_counters(dev, C), _lib.stream_ptr(dev))
+                                      int(relu_code), _reduce_counters(dev, C), _lib.stream_ptr(dev))
         else:
             rc = lib.dtf_bn_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(stats[0]),
                                 _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(dx),
                                 _lib.ptr(dres), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(coef), _lib.ptr(ws),
-                                ctypes.c_longlong(M), C, int(ctx.relu), _lib.stream_ptr(dev))
+                                ctypes.c_longlong(M), C, int(relu_code), _lib.stream_ptr(dev))
         if req is not None:
             req.x = req.stats = req.mask = req.partials = req.dy_ref = None
         _lib.check(rc, "bn_bwd")
@@ -246,7 +267,7 @@ class _BNActFn(torch.autograd.Function):
         if token is not None:
             token.masked_grad = (dy, dy._version, y)     # y holds the mask bytes saved by the forward pass
             dres = dy
-        return dx, dgb[0], dgb[1], None, None, None, None, None, dres, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, dres, None, None, None, None
 
 
 def batch_norm_deferred(x, gamma, beta, running_mean, running_var, momentum: float = 0.1, eps: float = 1e-5,
@@ -286,9 +307,16 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, mo
         if training:
             # the request rides on the output tensor: ops.conv picks it up from its input (see GradStatsRequest)
             req = GradStatsRequest() if (torch.is_grad_enabled() and x.requires_grad) else None
-            y = _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual, partials, req)
+            tok = None
+            if req is not None and not relu and residual is None:
+                from . import conv as _conv
+                tok = ForkToken() if _conv._bn_grad_stats else None
+            y = _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual, partials, req,
+                               False, tok)
             if req is not None:
                 setattr(y, _REQ_ATTR, req)
+            if tok is not None:
+                setattr(y, _TOKEN_ATTR, tok)
             return y
         scale = gamma * torch.rsqrt(running_var + eps)
         shift = beta - running_mean * scale

@@ -1090,6 +1090,54 @@ def test_masked_residual_gradient_hand_over_and_its_guards():
 
 
 @pytest.mark.gpu
+def test_plain_norm_reads_the_residual_gradient_with_the_mask_bits():
+    """Down-sampling branch: ``relu(bn_b(y) + bn_a(z))`` with ``bn_a`` a plain norm. With the hand-over ``bn_b``
+    writes no masked copy of its incoming gradient; ``bn_a`` reads that gradient together with the mask bits. The
+    gradients must match the path without the hand-over and fp32 autograd; a second use of ``bn_a``'s output fails
+    loudly."""
+    from distributed_tensorflow_amd.ops import conv, norm
+    torch.manual_seed(33)
+    N, C, H = 6, 64, 12
+    y = torch.randn(N, C, H, H, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    z = torch.randn(N, C, H, H, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    ga, ba = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.2
+    gb, bb = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.2
+    wts = torch.linspace(0.5, 1.5, y.numel(), device=DEV).reshape(y.shape)
+
+    def run(hand_over, extra_use=False):
+        conv.set_bn_stats(True, hand_over)
+        yi, zi = y.clone().requires_grad_(True), z.clone().requires_grad_(True)
+        gai, gbi = ga.clone().requires_grad_(True), gb.clone().requires_grad_(True)
+        st = lambda: (torch.zeros(C, device=DEV), torch.ones(C, device=DEV))
+        idt = norm.batch_norm_act(zi, gai, ba, *st(), True, 0.1, 1e-5, False)
+        assert (getattr(idt, norm._TOKEN_ATTR, None) is not None) == hand_over
+        out = norm.batch_norm_act(yi, gbi, bb, *st(), True, 0.1, 1e-5, True, idt)
+        loss = (out.float() * wts).sum()
+        if extra_use:
+            loss = loss + idt.float().sum()
+        loss.backward()
+        return [t.grad.float() for t in (yi, zi, gai, gbi)]
+
+    def reference():
+        yi, zi = y.float().requires_grad_(True), z.float().requires_grad_(True)
+        gai, gbi = ga.clone().requires_grad_(True), gb.clone().requires_grad_(True)
+        idt = torch.nn.functional.batch_norm(zi, None, None, gai, ba, True, 0.1, 1e-5)
+        out = torch.relu(torch.nn.functional.batch_norm(yi, None, None, gbi, bb, True, 0.1, 1e-5) + idt)
+        (out * wts).sum().backward()
+        return [t.grad for t in (yi, zi, gai, gbi)]
+    try:
+        a, b, r = run(True), run(False), reference()
+        for p, q, f in zip(a, b, r):
+            assert torch.allclose(p, q, atol=0.01 * float(q.abs().max()) + 1e-3, rtol=2e-2)
+            # against fp32: bf16 activations (a ReLU mask bit flips where the pre-activation rounds across zero)
+            assert float((p - f).norm() / f.norm()) < 6e-2
+        with pytest.raises(RuntimeError, match="only use"):
+            run(True, extra_use=True)
+    finally:
+        conv.set_bn_stats(True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(4, 64, 56, 3, 2, 1), (3, 16, 17, 3, 2, 1), (2, 32, 12, 2, 2, 0)])
 def test_norm_relu_max_pool_in_one_pass_matches_the_separate_kernels(cfg):
     from distributed_tensorflow_amd.ops import norm, pool
