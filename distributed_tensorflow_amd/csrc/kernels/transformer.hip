@@ -94,23 +94,29 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const unsigned short* __
 }
 
 // dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) (+ dres_in when given);
-// per-block partial sums of dgamma = sum g*xhat and dbeta = sum g go to part[block][2][H].
-template <int CH, typename P>
+// per-block partial sums of dgamma = sum g*xhat and dbeta = sum g go to part[block][NS][H]. CS (NS = 3): a third row
+// holds the column sums of dx as stored (rounded to bf16) -- the bias gradient of the linear layer whose output this
+// norm normalised, which then needs no pass of its own over dx.
+template <int CH, typename P, bool CS>
 __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const unsigned short* __restrict__ x,
                                                         const unsigned short* __restrict__ dy,
                                                         const unsigned short* __restrict__ dres_in,
                                                         const P* __restrict__ gamma, const float* __restrict__ stats,
                                                         unsigned short* __restrict__ dx, float* __restrict__ part,
                                                         long long rows, int H, int rows_per_block) {
-  __shared__ float red[2][4][64 * CH * 8 / 4 + 1];  // reduced in four rounds to bound LDS (see below)
+  constexpr int NS = CS ? 3 : 2;
+  __shared__ float red[NS][4][64 * CH * 8 / 4 + 1];  // reduced in four rounds to bound LDS (see below)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nch = H >> 3;
-  float dg[CH][8], db[CH][8], gam[CH][8];
+  float dg[CH][8], db[CH][8], dxs[CS ? CH : 1][8];
+#pragma unroll
+  for (int c = 0; c < (CS ? CH : 1); ++c)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dxs[c][k] = 0.f;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { dg[c][k] = 0.f; db[c][k] = 0.f; gam[c][k] = 0.f; }
-    if (lane + 64 * c < nch) t_ldp<P>(gamma + (lane + 64 * c) * 8, gam[c]);
+    for (int k = 0; k < 8; ++k) { dg[c][k] = 0.f; db[c][k] = 0.f; }
   }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long r1 = min(rows, r0 + rows_per_block);
@@ -124,12 +130,18 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const unsigned short* __
       if (ch < nch) {
         t_ld8(x + row * H + ch * 8, xh[c]);
         t_ld8(dy + row * H + ch * 8, g[c]);
+        // gamma is fetched per row (a cache hit) rather than held for the whole loop: 16 registers that decide
+        // whether four waves or three fit a SIMD; the laundered index keeps the compiler from hoisting the load
+        float gam[8];
+        int go = ch * 8;
+        asm volatile("" : "+v"(go));
+        t_ldp<P>(gamma + go, gam);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           xh[c][k] = (xh[c][k] - mean) * rstd;
           dg[c][k] = fmaf(g[c][k], xh[c][k], dg[c][k]);
           db[c][k] += g[c][k];
-          g[c][k] *= gam[c][k];
+          g[c][k] *= gam[k];
           s1 += g[c][k];
           s2 = fmaf(g[c][k], xh[c][k], s2);
         }
@@ -151,12 +163,17 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const unsigned short* __
           for (int k = 0; k < 8; ++k) o[k] += r[k];
         }
         t_st8(dx + row * H + ch * 8, o);
+        if (CS) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dxs[c][k] += bf16_to_f32(f32_to_bf16(o[k]));
+        }
       }
     }
   }
   // combine the 4 waves' partials: wave w adds into wave 0's registers through LDS, 2 values at a time
-  float* pg = part + ((long long)blockIdx.x * 2) * H;
+  float* pg = part + ((long long)blockIdx.x * NS) * H;
   float* pb = pg + H;
+  float* px = pb + H;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
 #pragma unroll
@@ -164,28 +181,34 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(const unsigned short* __
       __syncthreads();
       red[0][wid][lane * 2] = dg[c][k]; red[0][wid][lane * 2 + 1] = dg[c][k + 1];
       red[1][wid][lane * 2] = db[c][k]; red[1][wid][lane * 2 + 1] = db[c][k + 1];
+      if (CS) { red[NS - 1][wid][lane * 2] = dxs[CS ? c : 0][k]; red[NS - 1][wid][lane * 2 + 1] = dxs[CS ? c : 0][k + 1]; }
       __syncthreads();
       if (wid == 0 && lane + 64 * c < nch) {
         const int col = (lane + 64 * c) * 8 + k;
-        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, x0 = 0.f, x1 = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           a0 += red[0][w][lane * 2]; a1 += red[0][w][lane * 2 + 1];
           b0 += red[1][w][lane * 2]; b1 += red[1][w][lane * 2 + 1];
+          if (CS) { x0 += red[NS - 1][w][lane * 2]; x1 += red[NS - 1][w][lane * 2 + 1]; }
         }
         pg[col] = a0; pg[col + 1] = a1; pb[col] = b0; pb[col + 1] = b1;
+        if (CS) { px[col] = x0; px[col + 1] = x1; }
       }
     }
   }
 }
 
-// out[2][H]: column sums of part[n_part][2][H]; 32 columns per block (see partials_col_sum).
+// column sums of part[n_part][ns][H] (ns = 2, or 3 with the sums of dx); 32 columns per block (see partials_col_sum).
 __global__ __launch_bounds__(kBlock) void ln_bwd_finalize_kernel(const float* __restrict__ part, int n_part, int H,
-                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                                 int ns, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ dxsum) {
   float s;
-  if (!partials_col_sum(part, n_part, 2LL * H, 2 * H, s)) return;
+  if (!partials_col_sum(part, n_part, (long long)ns * H, ns * H, s)) return;
   const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  if (c < H) dgamma[c] = s; else dbeta[c - H] = s;
+  if (c < H) dgamma[c] = s;
+  else if (c < 2 * H) dbeta[c - H] = s;
+  else dxsum[c - 2 * H] = s;
 }
 
 // ------------------------------------------------------------------------------ softmax
@@ -302,25 +325,28 @@ DTF_API int dtf_ln_bwd_num_partials(long long rows) {
   return (int)(nb < 1 ? 1 : nb);
 }
 
-// part: fp32 [n_partials * 2 * H]
+// part: fp32 [n_partials * (dxsum ? 3 : 2) * H]. dxsum (optional, fp32 [H]): column sums of dx.
 DTF_API int dtf_ln_bwd(const void* x, const void* dy, const void* dres_in, const void* gamma, const float* stats,
                        void* dx, float* dgamma, float* dbeta, float* part, long long rows, int H, int param_dtype,
-                       hipStream_t stream) {
+                       float* dxsum, hipStream_t stream) {
   if (rows <= 0) return 0;
   const int ch = ch_for(H);
   if (H % 8 || ch == 0 || ch > 4) return -1;
   const int nb = dtf_ln_bwd_num_partials(rows);
   const int rpb = (int)((rows + nb - 1) / nb);
-#define LNB(CHN, P)                                                                                          \
-  hipLaunchKernelGGL((ln_bwd_kernel<CHN, P>), dim3(nb), dim3(kBlock), 0, stream, (const unsigned short*)x,  \
-                     (const unsigned short*)dy, (const unsigned short*)dres_in, (const P*)gamma, stats,     \
+#define LNB(CHN, P, CS)                                                                                          \
+  hipLaunchKernelGGL((ln_bwd_kernel<CHN, P, CS>), dim3(nb), dim3(kBlock), 0, stream, (const unsigned short*)x,  \
+                     (const unsigned short*)dy, (const unsigned short*)dres_in, (const P*)gamma, stats,         \
                      (unsigned short*)dx, part, rows, H, rpb)
-#define LNB_D(CHN) do { if (param_dtype == 0) LNB(CHN, float); else LNB(CHN, unsigned short); } while (0)
+#define LNB_P(CHN, CS) do { if (param_dtype == 0) LNB(CHN, float, CS); else LNB(CHN, unsigned short, CS); } while (0)
+#define LNB_D(CHN) do { if (dxsum) LNB_P(CHN, true); else LNB_P(CHN, false); } while (0)
   switch (ch) { case 1: LNB_D(1); break; case 2: LNB_D(2); break; default: LNB_D(4); }
 #undef LNB_D
+#undef LNB_P
 #undef LNB
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * H + 31) / 32), dim3(kBlock), 0, stream, part, nb, H, dgamma,
-                     dbeta);
+  const int ns = dxsum ? 3 : 2;
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((ns * H + 31) / 32), dim3(kBlock), 0, stream, part, nb, H, ns, dgamma,
+                     dbeta, dxsum);
   return (int)hipGetLastError();
 }
 

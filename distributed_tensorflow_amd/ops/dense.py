@@ -79,12 +79,24 @@ class _LinearFn(torch.autograd.Function):
         gw = _gemm.gemm_tn(g, x2) if ctx.needs_input_grad[1] else None    # [N, K]
         gb = None
         if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
-            gb = _gemm.col_sum(g, dtype=ctx.bias_dtype)
+            gb = _bias_grad(gy, g, ctx.bias_dtype) if ctx.drop is None and ctx.activation is None \
+                else _gemm.col_sum(g, dtype=ctx.bias_dtype)
         if gx is not None:
             gx = gx.reshape(ctx.x_shape)
             if g_alias is not None:
                 gx = gx + g_alias
         return gx, gw, gb, None, None
+
+
+def _bias_grad(gy: torch.Tensor, g: torch.Tensor, dtype) -> torch.Tensor:
+    """Column sums of the output gradient ``g`` (``gy`` as a matrix): taken from the LayerNorm backward that
+    produced ``gy`` when it summed them on the way (``ops.layernorm.take_col_sum``), else a pass over ``g``."""
+    if gy.is_cuda and gy.dtype == torch.bfloat16:
+        from . import layernorm as _ln
+        cs = _ln.take_col_sum(gy)
+        if cs is not None:
+            return cs if cs.dtype == dtype else cs.to(dtype)
+    return _gemm.col_sum(g, dtype=dtype)
 
 
 def _padded_cols(n: int) -> int:
@@ -248,7 +260,7 @@ class _FfnForkFn(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1]).contiguous()
         M, Fd = h.shape
         gw2 = _gemm.gemm_tn(g2, h) if ctx.needs_input_grad[3] else None
-        gb2 = _gemm.col_sum(g2, dtype=ctx.bias_dtypes[1]) if ctx.needs_input_grad[4] else None
+        gb2 = _bias_grad(gy, g2, ctx.bias_dtypes[1]) if ctx.needs_input_grad[4] else None
         g1 = _gemm.gemm256(_gemm.NN, g2, w2, M, Fd, g2.shape[1], mul=d)            # (g2 W2) * gelu'(pre)
         gw1 = _gemm.gemm_tn(g1, x2) if ctx.needs_input_grad[1] else None
         gb1 = _gemm.col_sum(g1, dtype=ctx.bias_dtypes[0]) if ctx.needs_input_grad[2] else None

@@ -26,6 +26,26 @@ def _scratch(device, numel):
     return t
 
 
+# Hand-over to the linear layer whose output a norm normalised: the norm's backward kernel also sums the columns of
+# the gradient dx it writes -- that layer's bias gradient -- and leaves them here under dx's address. The entry keeps
+# dx alive (its address cannot be reused) and its version counter; the taker checks both, so a gradient that autograd
+# summed with another one (new tensor, or in place: new version) never matches. At most two entries are kept.
+_handed: dict = {}
+_hand_over = __import__("os").environ.get("DTF_LN_BIAS_GRAD", "1") != "0"
+
+
+def take_col_sum(g: torch.Tensor):
+    """fp32 column sums of ``g`` (viewed as ``[rows, H]``) when ``g`` is, untouched, the input gradient the last
+    LayerNorm backward produced; ``None`` otherwise."""
+    ent = _handed.pop(g.data_ptr(), None) if _handed else None
+    if ent is None:
+        return None
+    dx, version, cs = ent
+    if g._version != version or g.numel() != dx.numel() or g.shape[-1] != cs.numel() or g.dtype != dx.dtype:
+        return None
+    return cs
+
+
 def _fast(x, gamma):
     H = x.shape[-1]
     return (x.is_cuda and x.dtype == torch.bfloat16 and H % 8 == 0 and H <= 2048 and x.is_contiguous()
@@ -66,12 +86,17 @@ class _LNFn(torch.autograd.Function):
         dx = torch.empty_like(xin)
         lib = _lib.kernels()
         nb = lib.dtf_ln_bwd_num_partials(ctypes.c_longlong(rows))
-        part = _scratch(dev, nb * 2 * H)
-        dgb = torch.empty(2, H, dtype=torch.float32, device=dev)
+        part = _scratch(dev, nb * 3 * H)
+        dgb = torch.empty(3, H, dtype=torch.float32, device=dev)
         rc = lib.dtf_ln_bwd(_lib.ptr(xin), _lib.ptr(dy), _lib.ptr(dres_in), _lib.ptr(gamma), _lib.ptr(stats), _lib.ptr(dx),
                             _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(part), ctypes.c_longlong(rows), H,
-                            _lib.dtype_code(gamma.dtype), _lib.stream_ptr(dev))
+                            _lib.dtype_code(gamma.dtype), _lib.ptr(dgb[2]) if _hand_over else None,
+                            _lib.stream_ptr(dev))
         _lib.check(rc, "ln_bwd")
+        if _hand_over:
+            while len(_handed) >= 2:
+                _handed.pop(next(iter(_handed)))
+            _handed[dx.data_ptr()] = (dx, dx._version, dgb[2])
         return dx, (dx if ctx.has_res else None), dgb[0].to(gamma.dtype), dgb[1].to(gamma.dtype), None, None
 
 

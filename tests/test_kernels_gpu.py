@@ -361,6 +361,51 @@ def test_layer_norm_matches_torch(rows, H, pdt, use_res):
     torch.testing.assert_close(b1.grad.float() / sc, br.grad / sc, rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize("rows,H,N", [(300, 256, 768), (4096, 3072, 768), (65, 128, 40)])
+def test_layer_norm_backward_hands_the_bias_gradient_to_the_linear_layer(rows, H, N):
+    """``LN(x W^T + b + res)``: the norm's backward kernel sums the columns of the gradient it writes, the linear
+    layer takes them as its bias gradient instead of a pass of its own. Same result as without the hand-over and as
+    fp32 autograd; a gradient that is not the norm's untouched output is never matched."""
+    from distributed_tensorflow_amd.ops import dense, layernorm
+    torch.manual_seed(rows + H)
+    x = torch.randn(rows, H, device=DEV).bfloat16()
+    w = (torch.randn(N, H, device=DEV) / H ** 0.5).bfloat16()
+    b = torch.randn(N, device=DEV).bfloat16()
+    res = torch.randn(rows, N, device=DEV).bfloat16()
+    gamma, beta = torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV)
+    wts = torch.rand(rows, N, device=DEV) + 0.5
+
+    def run(hand_over, second_use=False):
+        layernorm._hand_over = hand_over
+        layernorm._handed.clear()
+        bi, wi = b.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = dense.linear(x, wi, bi)
+        out = layernorm.layer_norm(y, gamma, beta, 1e-12, residual=res)
+        loss = (out.float() * wts).sum()
+        if second_use:
+            loss = loss + (y.float() * 0.5).sum()        # autograd then sums two gradients of y: no match
+        loss.backward()
+        taken = hand_over and not layernorm._handed
+        return bi.grad.float(), wi.grad.float(), taken
+    try:
+        gb1, gw1, taken = run(True)
+        assert taken, "the linear layer did not pick the column sums up"
+        gb0, gw0, _ = run(False)
+        gb2, _, taken2 = run(True, second_use=True)
+        assert not taken2
+    finally:
+        layernorm._hand_over = True
+        layernorm._handed.clear()
+    wf, bf = w.float().requires_grad_(True), b.float().requires_grad_(True)
+    yf = x.float() @ wf.t() + bf
+    (torch.nn.functional.layer_norm(yf + res.float(), (N,), gamma, beta, 1e-12) * wts).sum().backward()
+    tol = 2e-2 * float(bf.grad.abs().max()) + 1e-2
+    assert torch.allclose(gb1, gb0, atol=tol, rtol=2e-2)
+    assert torch.allclose(gb1, bf.grad, atol=3 * tol, rtol=5e-2)
+    assert torch.equal(gw1, gw0)
+    assert torch.allclose(gb2, bf.grad + 0.5 * rows, atol=3 * tol + 0.02 * rows, rtol=5e-2)
+
+
 @pytest.mark.parametrize("B,S,nh,hd", [(2, 128, 4, 64), (3, 512, 2, 64), (1, 64, 3, 32), (2, 72, 2, 64)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_attention_matches_reference(B, S, nh, hd, masked):
