@@ -255,8 +255,10 @@ __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(const unsigned sho
   }
 }
 
-// dx = A*dy' + K*x + C0 ; dres = dy' (only written when dres != null)
-template <int R, bool NT>
+// dx = A*dy' + K*x + C0 ; dres = dy' (only written when dres != null). The ReLU form (RL = the `relu` argument of
+// dtf_bn_bwd) is a template parameter: each form then keeps only its own operands in registers (the recomputed mask of
+// form 2 needs 16 for scale / shift that the mask-bit form 3 does not), which decides how many waves fit a SIMD.
+template <int R, bool NT, int RL>
 __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(const unsigned short* __restrict__ x,
                                                               const unsigned short* __restrict__ dy,
                                                               const unsigned short* __restrict__ y,
@@ -265,26 +267,26 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(const unsigned sho
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               unsigned short* __restrict__ dx,
-                                                              unsigned short* __restrict__ dres, long long M, int C,
-                                                              int relu) {
+                                                              unsigned short* __restrict__ dres, long long M, int C) {
+  constexpr int relu = RL;
   const int c8 = C >> 3;
   const long long n8 = M * c8;
   const bool fixed = (kBlock % c8) == 0;
   for (long long base = (long long)blockIdx.x * (kBlock * R); base < n8; base += (long long)gridDim.x * (kBlock * R)) {
     const long long i0 = base + threadIdx.x;
-    u16x8 xr[R], gr[R], yr[R];
-    unsigned mbits[R];
+    u16x8 xr[R], gr[R], yr[RL == 1 ? R : 1];
+    unsigned mbits[RL == 3 ? R : 1];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       const long long i = i0 + k * kBlock;
       if (i < n8) {
         xr[k] = ldraw<NT>(x + i * 8);
         gr[k] = ldraw<NT>(dy + i * 8);
-        if (relu == 1) yr[k] = ldraw<NT>(y + i * 8);
-        else if (relu == 3) mbits[k] = reinterpret_cast<const unsigned char*>(y)[i];
+        if (relu == 1) yr[RL == 1 ? k : 0] = ldraw<NT>(y + i * 8);
+        else if (relu == 3) mbits[RL == 3 ? k : 0] = reinterpret_cast<const unsigned char*>(y)[i];
       }
     }
-    float a[8], kk[8], z[8], sa[8], sb[8];
+    float a[8], kk[8], z[8], sa[RL == 2 ? 8 : 1], sb[RL == 2 ? 8 : 1];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       const long long i = i0 + k * kBlock;
@@ -292,19 +294,19 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(const unsigned sho
       if (k == 0 || !fixed) {
         const int c = (int)(i % c8) << 3;
         ld8f(cA + c, a); ld8f(cK + c, kk); ld8f(c0 + c, z);
-        if (relu == 2) { ld8f(scale + c, sa); ld8f(shift + c, sb); }
+        if constexpr (RL == 2) { ld8f(scale + c, sa); ld8f(shift + c, sb); }
       }
       float v[8], g[8];
       cvt8(xr[k], v); cvt8(gr[k], g);
-      if (relu == 1) {
+      if constexpr (RL == 1) {
         float o[8];
         cvt8(yr[k], o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
-      } else if (relu == 3) {
+      } else if constexpr (RL == 3) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = (mbits[k] >> e) & 1u ? g[e] : 0.f;
-      } else if (relu == 2) {
+      } else if constexpr (RL == 2) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = fmaf(v[e], sa[e], sb[e]) > 0.f ? g[e] : 0.f;
       }
@@ -340,13 +342,18 @@ static void launch_apply_fwd(const void* x, const void* res, const float* scale,
 static void launch_apply_bwd(const void* x, const void* dy, const void* y, const float* coef, const float* scale,
                              const float* shift, void* dx, void* dres, long long M, int C, int relu,
                              hipStream_t stream) {
-#define AB(R, NT)                                                                                                       \
-  hipLaunchKernelGGL((bn_apply_bwd_kernel<R, NT>), dim3(grid_stream(M * (C / 8), kBlock * R)), dim3(kBlock), 0, stream, \
+#define AB3(R, NT, RL)                                                                                                  \
+  hipLaunchKernelGGL((bn_apply_bwd_kernel<R, NT, RL>), dim3(grid_stream(M * (C / 8), kBlock * R)), dim3(kBlock), 0, stream, \
                      (const unsigned short*)x, (const unsigned short*)dy, (const unsigned short*)y, coef, coef + C, \
-                     coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C, relu)
+                     coef + 2 * C, scale, shift, (unsigned short*)dx, (unsigned short*)dres, M, C)
+#define AB(R, NT)                                                                                                       \
+  do {                                                                                                                  \
+    if (relu == 3) AB3(R, NT, 3); else if (relu == 2) AB3(R, NT, 2); else if (relu == 1) AB3(R, NT, 1); else AB3(R, NT, 0); \
+  } while (0)
   if (g_apply_nt) { if (g_apply_rows == 4) AB(4, true); else if (g_apply_rows == 2) AB(2, true); else AB(1, true); }
   else { if (g_apply_rows == 4) AB(4, false); else if (g_apply_rows == 2) AB(2, false); else AB(1, false); }
 #undef AB
+#undef AB3
 }
 
 static int bn_partials_for(long long M, int C) {

@@ -27,6 +27,9 @@ def _scratch(device, numel: int) -> torch.Tensor:
     return t
 
 
+# A/B switch: every norm with a ReLU writes mask bits in its forward pass (form 3 of the backward kernels), also
+# those without a residual, whose mask the backward pass can recompute from the input (form 2)
+_mask_all = __import__("os").environ.get("DTF_BN_MASK_ALL", "0") == "1"
 _counters: dict = {}
 # Off by default: measured on MI355X (ResNet-50, batch 1024) the single launch takes 13.7-15.2 us against 8.8 + 5.5 us
 # for the fold and finalize kernels it replaces (80 launches fewer per step, 13,640 vs 13,700 images/s): the device-
@@ -176,7 +179,7 @@ class _BNActFn(torch.autograd.Function):
         # from x alone, so the forward pass writes it as one bit per element (1/16 of re-reading y);
         # without a residual it is recomputed from x and nothing is kept
         ctx.has_res = residual is not None
-        ctx.relu = 0 if not relu else (3 if residual is not None else 2)
+        ctx.relu = 0 if not relu else (3 if (residual is not None or _mask_all) else 2)
         ctx.fork_token = getattr(residual, _TOKEN_ATTR, None) if (residual is not None and relu) else None
         mask = torch.empty(M * C // 8, dtype=torch.uint8, device=dev) if ctx.relu == 3 else None
         if partials is not None:
