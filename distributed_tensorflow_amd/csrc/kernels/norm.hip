@@ -38,7 +38,8 @@ __device__ __forceinline__ void ld8f(const float* p, float (&o)[8]) {
 // MODE 0: s0 = sum x, s1 = sum x^2
 // MODE 1: s0 = sum dy', s1 = sum dy' * (x - mean) * invstd,  dy' = relu ? dy * (y > 0) : dy
 // grid = (n_partials, channel_chunks); a channel chunk is up to 2048 channels (256 threads x 8).
-template <int MODE>
+// RL (MODE 1): the ReLU form, a template parameter so that each form keeps only its own operands in registers.
+template <int MODE, int RL = 0>
 __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short* __restrict__ x,
                                                             const unsigned short* __restrict__ dy,
                                                             const unsigned short* __restrict__ y,
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* __restrict__ part,
-                                                            long long M, int C, int relu) {
+                                                            long long M, int C) {
+  constexpr int relu = RL;
   __shared__ float red[2][kBlock][8];
   const int cchunk = min(C, 2048);
   const int tpr = cchunk >> 3;                 // threads per row
@@ -55,10 +57,10 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short
   const int c0 = blockIdx.y * 2048 + tc * 8;
   const bool live = tr < rpb && c0 < C;
   float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float mu[8], is[8], sa[8], sb[8];
+  float mu[8], is[8], sa[RL == 2 ? 8 : 1], sb[RL == 2 ? 8 : 1];
   if (MODE == 1 && live) {
     ld8f(mean + c0, mu); ld8f(invstd + c0, is);
-    if (relu == 2) { ld8f(scale + c0, sa); ld8f(shift + c0, sb); }
+    if constexpr (RL == 2) { ld8f(scale + c0, sa); ld8f(shift + c0, sb); }
   }
   if (live) {
     const long long rstride = (long long)gridDim.x * rpb;
@@ -71,17 +73,17 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(const unsigned short
       } else {
         float g[8];
         ld8bf(dy + r * C + c0, g);
-        if (relu == 1) {
+        if constexpr (RL == 1) {
           float o[8];
           ld8bf(y + r * C + c0, o);
 #pragma unroll
           for (int k = 0; k < 8; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
-        } else if (relu == 3) {
+        } else if constexpr (RL == 3) {
           // one mask byte per 8 channels, written by the forward pass (y holds the byte array)
           const unsigned mb = reinterpret_cast<const unsigned char*>(y)[(r * C + c0) >> 3];
 #pragma unroll
           for (int k = 0; k < 8; ++k) g[k] = (mb >> k) & 1u ? g[k] : 0.f;
-        } else if (relu == 2) {
+        } else if constexpr (RL == 2) {
           // no residual: the forward output was relu(fma(x, scale, shift)); recompute its sign from x
 #pragma unroll
           for (int k = 0; k < 8; ++k) g[k] = fmaf(v[k], sa[k], sb[k]) > 0.f ? g[k] : 0.f;
@@ -379,7 +381,7 @@ DTF_API int dtf_bn_fwd_train(const void* x, const void* res, void* y, const floa
   const int nb = bn_partials_for(M, C);
   const dim3 grid(nb, (C + 2047) / 2048);
   hipLaunchKernelGGL(bn_partial_kernel<0>, grid, dim3(kBlock), 0, stream, (const unsigned short*)x, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
+                     nullptr, nullptr, nullptr, nullptr, workspace, M, C);
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb, gamma, beta,
                      run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
   launch_apply_fwd(x, res, scale, shift, y, mask_out, M, C, relu, stream);
@@ -572,9 +574,11 @@ DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float
   if (C % 8) return -1;
   const int nb = bn_partials_for(M, C);
   const dim3 grid(nb, (C + 2047) / 2048);
-  hipLaunchKernelGGL(bn_partial_kernel<1>, grid, dim3(kBlock), 0, stream, (const unsigned short*)x,
-                     (const unsigned short*)dy, (const unsigned short*)y, mean, invstd, scale, shift, workspace, M, C,
-                     relu);
+#define BP(RL)                                                                                                 \
+  hipLaunchKernelGGL((bn_partial_kernel<1, RL>), grid, dim3(kBlock), 0, stream, (const unsigned short*)x,       \
+                     (const unsigned short*)dy, (const unsigned short*)y, mean, invstd, scale, shift, workspace, M, C)
+  if (relu == 3) BP(3); else if (relu == 2) BP(2); else if (relu == 1) BP(1); else BP(0);
+#undef BP
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace, nb, gamma, mean,
                      invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 0);
   launch_apply_bwd(x, dy, y, coef, scale, shift, dx, dres, M, C, relu, stream);
@@ -1004,7 +1008,7 @@ DTF_API int dtf_bn_relu_maxpool_fwd_stats(const void* x, void* y, void* idx, con
   } else {
     np = bn_partials_for(M, C);
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(np, 1), dim3(kBlock), 0, stream, (const unsigned short*)x, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
+                       nullptr, nullptr, nullptr, nullptr, nullptr, workspace, M, C);
   }
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, part, np,
                      gamma, beta, run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);

@@ -27,9 +27,11 @@ def _scratch(device, numel: int) -> torch.Tensor:
     return t
 
 
-# A/B switch: every norm with a ReLU writes mask bits in its forward pass (form 3 of the backward kernels), also
-# those without a residual, whose mask the backward pass can recompute from the input (form 2)
-_mask_all = __import__("os").environ.get("DTF_BN_MASK_ALL", "0") == "1"
+# Every norm with a ReLU writes mask bits in its forward pass (form 3 of the backward kernels), also those without a
+# residual, whose mask the backward pass could recompute from the input (form 2): one byte per 8 elements more
+# traffic, but the backward kernels then need no scale / shift registers (66 against 89, seven waves per SIMD against
+# five): 13,964 against 13,906 images/s. ``DTF_BN_MASK_ALL=0`` restores the recomputed mask.
+_mask_all = __import__("os").environ.get("DTF_BN_MASK_ALL", "1") != "0"
 _counters: dict = {}
 # Off by default: measured on MI355X (ResNet-50, batch 1024) the single launch takes 13.7-15.2 us against 8.8 + 5.5 us
 # for the fold and finalize kernels it replaces (80 launches fewer per step, 13,640 vs 13,700 images/s): the device-
@@ -177,9 +179,10 @@ class _BNActFn(torch.autograd.Function):
             residual = residual.contiguous(memory_format=torch.channels_last)
         # relu mask for backward: with a residual the sign of the pre-activation cannot be recomputed
         # from x alone, so the forward pass writes it as one bit per element (1/16 of re-reading y);
-        # without a residual it is recomputed from x and nothing is kept
+        # without a residual it could be recomputed from x (see _mask_all)
         ctx.has_res = residual is not None
-        ctx.relu = 0 if not relu else (3 if (residual is not None or _mask_all) else 2)
+        # (a deferred norm runs no apply pass, so nothing would write the bits: it keeps the recomputed mask)
+        ctx.relu = 0 if not relu else (3 if (residual is not None or (_mask_all and not defer)) else 2)
         ctx.fork_token = getattr(residual, _TOKEN_ATTR, None) if (residual is not None and relu) else None
         mask = torch.empty(M * C // 8, dtype=torch.uint8, device=dev) if ctx.relu == 3 else None
         if partials is not None:
