@@ -145,8 +145,17 @@ class BasicBlock(nn.Module):
             self.down_bn = BNAct(cout, relu=False)
 
     def forward(self, x):
-        idt = x if self.down is None else _conv_bn(self.down, self.down_bn, x)
-        y = _conv_bn(self.conv1, self.bn1, x)
+        # as in Bottleneck: the alias xi carries the identity (or down-sampling) branch's gradient into conv1's
+        # data-gradient epilogue, so autograd runs no add kernel over the block input and the norm before this
+        # block sees a single consumer (its backward sums then come from that epilogue)
+        c1 = self.conv1
+        if self.training:
+            y, xi, st = conv_ops.conv2d_fork(x, c1.weight, c1.stride, c1.padding, bn_stats=True)
+            y = self.bn1(y, partials=st)
+        else:
+            y, xi = conv_ops.conv2d_fork(x, c1.weight, c1.stride, c1.padding)
+            y = self.bn1(y)
+        idt = xi if self.down is None else _conv_bn(self.down, self.down_bn, xi)
         return _conv_bn(self.conv2, self.bn2, y, residual=idt)
 
 
