@@ -41,7 +41,8 @@ def take_col_sum(g: torch.Tensor):
     if ent is None:
         return None
     dx, version, cs = ent
-    if g._version != version or g.numel() != dx.numel() or g.shape[-1] != cs.numel() or g.dtype != dx.dtype:
+    if (g._version != version or g.numel() != dx.numel() or g.shape[-1] != cs.numel() or g.dtype != dx.dtype
+            or not g.is_contiguous()):
         return None
     return cs
 
