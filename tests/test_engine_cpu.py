@@ -285,3 +285,32 @@ def test_package_import_keeps_the_conv_library_reference_kernels_out_of_its_sear
     importlib.reload(pkg)
     assert os.environ[names[0]] == "1"
     assert os.environ[names[1]] == "0" and os.environ[names[2]] == "0"
+
+
+def test_layer_norm_column_sum_hand_over_matches_only_the_untouched_gradient():
+    """``ops.layernorm.take_col_sum``: the sums recorded for a gradient are handed out once, and only for that very
+    tensor: same address, same version counter, same size, contiguous."""
+    from distributed_tensorflow_amd.ops import layernorm as ln
+    ln._handed.clear()
+    dx = torch.randn(6, 8)
+    cs = dx.sum(0)
+
+    def record():
+        ln._handed.clear()
+        ln._handed[dx.data_ptr()] = (dx, dx._version, cs)
+    record()
+    assert ln.take_col_sum(dx.reshape(-1, 8)) is cs          # a view of the same memory, untouched
+    assert ln.take_col_sum(dx) is None                       # handed out once
+    record()
+    assert ln.take_col_sum(dx.clone()) is None               # another tensor
+    assert ln.take_col_sum(dx[:3]) is None                   # same address, fewer rows
+    record()
+    dx.add_(1.0)                                             # summed into in place: the version counter moved
+    assert ln.take_col_sum(dx) is None
+    record()
+    assert ln.take_col_sum(dx.reshape(8, 6)) is None         # same memory read with another row length
+    ln._handed.clear()
+    # the CPU composition never records anything
+    x = torch.randn(4, 8, requires_grad=True)
+    ln.layer_norm(x, torch.ones(8), torch.zeros(8)).sum().backward()
+    assert not ln._handed
