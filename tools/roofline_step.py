@@ -33,7 +33,7 @@ def floors(d):
     if c == 0:
         flop = 2.0 * M * N * K * b
         rd = (K * (M + N) if d["layout"] == 2 else M * K + K * N) * 2 * b
-        wr = M * N * ob * b
+        wr = M * N * ob * b * (4 if d["up2"] else 1)     # up2 also writes the three zero pixels of every 2x2 patch
     else:
         NB, H, W, OH, OW, CI, CO, KH, KW, S = (d[k] for k in ("NB", "H", "W", "OH", "OW", "CI", "CO", "KH", "KW", "S"))
         flop = 2.0 * NB * OH * OW * CO * CI * KH * KW
