@@ -655,10 +655,13 @@ __global__ __launch_bounds__(kBlock) void bn_relu_maxpool_fwd_kernel(const unsig
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / g.OH, oh = row - n * g.OH;
     for (int ow = slot; ow < g.OW; ow += slots) {
-      float best[8];
-      unsigned char arg[8];
+      // One 32-bit key per element: the rounded, rectified value's bf16 bits above 255 - tap. The value is not
+      // negative, so its bits order like unsigned integers, and among equal values the larger low byte -- the earlier
+      // tap -- wins: an unsigned maximum per tap replaces the compare / select chain (first maximum wins, as in
+      // the unfused pool). Any tap beats the initial key 0.
+      unsigned key[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; arg[k] = 0; }
+      for (int k = 0; k < 8; ++k) key[k] = 0u;
 #pragma unroll 3
       for (int kh = 0; kh < K; ++kh) {
         const int ih = oh * S - P + kh;
@@ -669,19 +672,24 @@ __global__ __launch_bounds__(kBlock) void bn_relu_maxpool_fwd_kernel(const unsig
           if (iw < 0 || iw >= g.W) continue;
           float v[8];
           ld8bf(x + (((long long)n * g.H + ih) * g.W + iw) * g.C + c, v);
-          const unsigned char tap = (unsigned char)(kh * K + kw);
+          const unsigned code = 255u - (unsigned)(kh * K + kw);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const float f = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(v[k], sa[k], sb[k]), 0.f)));
-            if (f > best[k] || (f != f && best[k] == best[k])) { best[k] = f; arg[k] = tap; }   // first maximum wins
+          for (int k = 0; k < 8; k += 2) {
+            const float lo = fmaxf(fmaf(v[k], sa[k], sb[k]), 0.f), hi = fmaxf(fmaf(v[k + 1], sa[k + 1], sb[k + 1]), 0.f);
+            const unsigned pk = pack_bf16x2(lo, hi) & 0x7fff7fffu;       // (a negative zero must not outrank anything)
+            key[k] = max(key[k], (pk << 16) | code);
+            key[k + 1] = max(key[k + 1], (pk & 0xffff0000u) | code);
           }
         }
       }
       bp_u8x8 a;
+      u32x4_t out;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) a[k] = arg[k];
+      for (int k = 0; k < 8; ++k) a[k] = (unsigned char)(255u - (key[k] & 0xffu));
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) out[k >> 1] = (key[k] >> 16) | (key[k + 1] & 0xffff0000u);
       const long long o = ((long long)row * g.OW + ow) * g.C + c;
-      st8bf(y + o, best);
+      *reinterpret_cast<u32x4_t*>(y + o) = out;
       *reinterpret_cast<bp_u8x8*>(idx + o) = a;
     }
   }
