@@ -109,3 +109,21 @@ def test_bench_every_strategy_two_ranks(strategy):
     assert "forward" in r["phase_ms"] and "backward" in r["phase_ms"]
     if strategy in ("keras", "sync"):
         assert r["exposed_comm_fraction"] is not None
+
+
+def test_collective_harness_two_ranks_gloo():
+    """tools/bench_collectives.py over gloo: every back end that applies on the CPU (process-group all-reduce, the
+    five point-to-point schedules, reduce-scatter + all-gather) reproduces the exact sum and is timed."""
+    out = os.path.join(ROOT, "gpurun_out", "collectives_w2.json")
+    if os.path.exists(out):
+        os.remove(out)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_collectives.py"), "--gpus", "2", "--device", "cpu",
+           "--sizes-mib", "0.25", "--dtype", "fp32", "--iters", "2"]
+    p = subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    with open(out) as f:
+        d = json.load(f)
+    assert d["world"] == 2 and d["backend"] == "gloo"
+    names = {r["backend"] for r in d["results"]}
+    assert {"rccl", "custom:direct", "custom:ring", "custom:multiring", "custom:tree", "custom:oneshot", "rs+ag"} <= names
+    assert all(r["correct"] and r["us"] > 0 for r in d["results"])
