@@ -122,9 +122,17 @@ __device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ part, 
   float a0 = 0.f, a1 = 0.f;
   if (c < C) {
     int p = pl;
+    const long long st = (long long)2 * kFinLanes * C;   // kFinLanes partials ahead
+    for (; p + 7 * kFinLanes < n_part; p += 8 * kFinLanes) {      // 16 loads in flight (1024 partials: one round)
+      const float* q = part + (long long)p * 2 * C + c;
+      float x[8], y[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { x[i] = q[i * st]; y[i] = q[i * st + C]; }
+      a0 += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+      a1 += ((y[0] + y[1]) + (y[2] + y[3])) + ((y[4] + y[5]) + (y[6] + y[7]));
+    }
     for (; p + 3 * kFinLanes < n_part; p += 4 * kFinLanes) {
       const float* q = part + (long long)p * 2 * C + c;
-      const long long st = (long long)2 * kFinLanes * C;   // kFinLanes partials ahead
       float x0 = q[0], y0 = q[C], x1 = q[st], y1 = q[st + C], x2 = q[2 * st], y2 = q[2 * st + C], x3 = q[3 * st],
             y3 = q[3 * st + C];
       a0 += (x0 + x1) + (x2 + x3);
@@ -400,6 +408,12 @@ __global__ __launch_bounds__(kBlock) void bn_fold_partials_kernel(const float* _
   const float* q = part + (long long)r0 * width + e;
   float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
   int r = r0;
+  // eight loads in flight: the kernel is a chain of dependent round trips (98 rows per block behind a 56x56 layer)
+  for (; r + 7 < r1; r += 8, q += 8LL * width) {
+    const float x0 = q[0], x1 = q[width], x2 = q[2LL * width], x3 = q[3LL * width], x4 = q[4LL * width],
+                x5 = q[5LL * width], x6 = q[6LL * width], x7 = q[7LL * width];
+    a += x0 + x4; b += x1 + x5; c += x2 + x6; d += x3 + x7;
+  }
   for (; r + 3 < r1; r += 4, q += 4LL * width) {
     a += q[0]; b += q[width]; c += q[2LL * width]; d += q[3LL * width];
   }
