@@ -529,7 +529,7 @@ static void launch_reduce_finalize(const float* part, int n_rows, float* ws, uns
 // counters a launch of the fused reduction needs (one per 32 channels), all zero before and after
 DTF_API int dtf_bn_reduce_counters(int C) { return (C + kRfCh - 1) / kRfCh; }
 
-constexpr int kFoldRows = 256;            // rows a fold leaves
+constexpr int kFoldRows = 512;            // rows a fold leaves
 constexpr int kFoldAbove = kBnMaxPartials; // the finalize kernels take up to this many rows directly
 
 // dtf_bn_fwd_train with the batch statistics already reduced to partial rows by the producer of x: col_stats is

@@ -190,7 +190,7 @@ class _BNActFn(torch.autograd.Function):
             if partials.dtype != torch.float32 or partials.dim() != 3 or tuple(partials.shape[1:]) != (2, C) \
                     or not partials.is_contiguous():
                 raise ValueError("batch_norm_act: partials must be a contiguous fp32 [rows, 2, C] tensor")
-            ws = _scratch(dev, max(nb, 256) * 2 * C)
+            ws = _scratch(dev, max(nb, 512) * 2 * C)
             rc = lib.dtf_bn_fwd_train_stats(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma),
                                             _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]),
                                             _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
@@ -254,7 +254,7 @@ class _BNActFn(torch.autograd.Function):
         if req is not None and req.matches(dy):
             # the convolution that consumed the output already reduced this very gradient
             part = req.partials
-            ws = _scratch(dev, max(nb, 256) * 2 * C)
+            ws = _scratch(dev, max(nb, 512) * 2 * C)
             rc = lib.dtf_bn_bwd_stats(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(stats[0]),
                                       _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(dx),
                                       _lib.ptr(dres), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(coef),
@@ -356,7 +356,7 @@ class _BNReluPoolFn(torch.autograd.Function):
         stats = torch.empty(4, C, dtype=torch.float32, device=dev)
         lib = _lib.kernels()
         nb = lib.dtf_bn_num_partials(ctypes.c_longlong(N * H * W), C)
-        ws = _scratch(dev, max(nb, 256) * 2 * C)
+        ws = _scratch(dev, max(nb, 512) * 2 * C)
         if partials is not None and (partials.dtype != torch.float32 or partials.dim() != 3
                                      or tuple(partials.shape[1:]) != (2, C) or not partials.is_contiguous()):
             raise ValueError("batch_norm_relu_max_pool: partials must be a contiguous fp32 [rows, 2, C] tensor")
