@@ -24,8 +24,10 @@ _ACT = {None: 0, "relu": 1, "gelu": 2}
 NT, NN, TN = 0, 1, 2
 _N_CU = 256
 _SPLIT_BLOCKS_WIDE = int(os.environ.get("DTF_GEMM_SPLIT_BLOCKS_WIDE", "4"))       # ... and for wider ones
-_SPLIT_BLOCKS_PER_CU = int(os.environ.get("DTF_GEMM_SPLIT_BLOCKS_PER_CU", "6"))   # split-K target for products of <= 16 tiles
-# (with the blocks of a split sharing an XCD: 6 / 4 measured 76.0 ms per ResNet-50 step, 4 / 3 77.0, 8 / 4 75.9, 12 / 6 76.5)
+_SPLIT_BLOCKS_PER_CU = int(os.environ.get("DTF_GEMM_SPLIT_BLOCKS_PER_CU", "4"))   # split-K target for products of <= 16 tiles
+# (with the blocks of a split sharing an XCD: 6 / 4 measured 76.0 ms per ResNet-50 step, 4 / 3 77.0, 8 / 4 75.9, 12 / 6 76.5;
+# re-measured with the weight gradients on the side stream and the leaner norm kernels, same box, images/s: 4 / 4 14,028-14,048,
+# 3 / 4 14,035, 6 / 4 13,985-14,010, 8 / 4 13,939, 4 / 5 13,935, 6 / 6 13,920 -- fewer fp32 slabs to write and re-read)
 
 
 def _ok2d(t: torch.Tensor) -> bool:
