@@ -121,7 +121,7 @@ class _SideGrads:
 
 
 side_grads = _SideGrads()
-_SIDE_MIN_ELEMS = 1 << 25      # operand elements (gradient + activation) from which a weight gradient takes the side stream
+_SIDE_MIN_ELEMS = int(os.environ.get("DTF_WGRAD_SIDE_MIN", str(1 << 25)))      # operand elements (gradient + activation) from which a weight gradient takes the side stream
 
 
 class _ConvFn(torch.autograd.Function):
