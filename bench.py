@@ -157,10 +157,12 @@ def main() -> int:
         loss = step(x, y)
     sync()
     dt = time.perf_counter() - t0
+    dt_min = dt
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64 if dev.type == "cpu" else torch.float32, device=dev)
+        # the slowest rank's time counts; the fastest rank's is reported next to it (the spread between ranks)
+        t = torch.tensor([dt, -dt], dtype=torch.float64 if dev.type == "cpu" else torch.float32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        dt, dt_min = float(t[0]), -float(t[1])
     loss_v = float(loss)
 
     # ---- after the timed region: where the time goes, and whether the replicas still agree
@@ -204,6 +206,7 @@ def main() -> int:
                        "conv1x1": conv.get_conv1x1_backend(), "convkxk": conv.get_convkxk_backend(),
                        "hip_graph": st.cfg.graph},
             "ranks_seen": ranks_seen, "comm_backend": comm.backend if world > 1 else "none (single rank)",
+            "ms_per_step_fastest_rank": round(dt_min / a.steps * 1e3, 3),
             "buckets": {"count": len(buckets), "cap_mib": bucket_mb, "total_mib": round(sum(buckets) / 2 ** 20, 2),
                         "largest_mib": round(max(buckets) / 2 ** 20, 2)},
             "phase_ms": phase_ms, "exposed_comm_fraction": exposed, "replicas_agree": agree,
