@@ -59,6 +59,8 @@ def main() -> int:
                          "uint8 images in host memory, gathered per step by the native loader threads, uploaded on a copy "
                          "stream one step ahead and normalised on the GPU (ResNet-50 only)")
     ap.add_argument("--phase-steps", type=int, default=3, help="untimed steps after the timed loop that measure per-phase device time (0 = skip)")
+    ap.add_argument("--comm-timeout-s", type=float, default=1200.0,
+                    help="every collective of the process group fails after this many seconds instead of blocking")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -99,7 +101,7 @@ def main() -> int:
         conv.set_conv1x1_backend(a.conv1x1)
     if a.convkxk:
         conv.set_convkxk_backend(a.convkxk)
-    comm = Comm.from_env(dev, timeout_s=1200.0) if world > 1 else Comm(0, 1, dev)
+    comm = Comm.from_env(dev, timeout_s=a.comm_timeout_s) if world > 1 else Comm(0, 1, dev)
     bucket_mb = a.bucket_mb or bench_lib.BUCKET_MB
     gdt = torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32
     if a.model == "resnet50":

@@ -127,19 +127,30 @@ class CustomAllReduceStrategy(Strategy):
 
 
 def circulant_neighbours(rank: int, world: int, degree: int) -> list[int]:
-    """Neighbours of ``rank`` in the circulant graph with offsets +-1, +-2, ... (``degree`` of them;
-    an odd degree adds the antipodal node when ``world`` is even)."""
-    degree = max(0, min(degree, world - 1))
+    """Neighbours of ``rank`` in the undirected circulant graph of ``world`` nodes in which every node has
+    exactly ``degree`` neighbours: offsets +-1 ... +-(degree // 2), plus the antipodal node ``rank + world / 2``
+    when ``degree`` is odd. ``j`` is in the list of ``i`` exactly when ``i`` is in the list of ``j``, for every
+    degree -- a one-directional edge would leave a send without its matching receive. A degree of
+    ``world - 1`` or more gives the complete graph; an odd degree on an odd number of nodes does not exist
+    (the degrees of a graph sum to an even number) and raises."""
+    degree = max(0, min(int(degree), world - 1))
+    if degree == world - 1:
+        return [(rank + k) % world for k in range(1, world)]
+    if degree % 2 == 1 and world % 2 == 1:
+        raise ValueError(f"no {degree}-regular graph on {world} nodes: an odd degree needs an even number of nodes")
     out: list[int] = []
-    k = 1
-    while len(out) < degree:
-        for cand in ((rank + k) % world, (rank - k) % world):
-            if cand != rank and cand not in out and len(out) < degree:
-                out.append(cand)
-        k += 1
-        if k > world:
-            break
+    for k in range(1, degree // 2 + 1):
+        out += [(rank + k) % world, (rank - k) % world]
+    if degree % 2 == 1:
+        out.append((rank + world // 2) % world)
+    assert len(set(out)) == degree and rank not in out
     return out
+
+
+def graph_is_undirected(world: int, degree: int) -> bool:
+    """Every edge of the circulant graph is seen from both of its ends."""
+    nb = [set(circulant_neighbours(r, world, degree)) for r in range(world)]
+    return all(i in nb[j] for i in range(world) for j in nb[i])
 
 
 class GraphStrategy(Strategy):
@@ -150,10 +161,10 @@ class GraphStrategy(Strategy):
         super().__init__(model, comm, cfg, optimizer, metrics)
         self.optimizer = FlatOptimizer(self.flat, optimizer)
         self.broadcast_initial(0)
-        if degree % 2 == 1 and comm.world % 2 == 1 and degree < comm.world - 1:
-            raise ValueError("an odd degree needs an even number of nodes (the graph must be undirected)")
-        self.degree = min(degree, comm.world - 1)
-        self.neighbours = circulant_neighbours(comm.rank, comm.world, self.degree)
+        self.degree = max(0, min(int(degree), comm.world - 1))
+        self.neighbours = circulant_neighbours(comm.rank, comm.world, self.degree)   # raises for odd x odd
+        if not graph_is_undirected(comm.world, self.degree):
+            raise AssertionError(f"graph of degree {self.degree} on {comm.world} nodes has a one-directional edge")
         self.gossip_every = max(1, gossip_every)
         self._recv = [torch.empty_like(self.flat.master) for _ in self.neighbours]
         self._steps = 0

@@ -90,19 +90,25 @@ def test_bench_two_ranks_under_torchrun_gloo():
     _check(lines[0], 2)
 
 
-@pytest.mark.parametrize("strategy", ["keras", "custom:ring", "custom:direct", "sync", "async", "graph:1"])
-def test_bench_every_strategy_two_ranks(strategy):
-    """The benchmark drives every strategy; the JSON proves that two ranks took part, shows the phases and reports
-    that the replicas agree after the run."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu",
-           "--model", "bert-tiny", "--batch", "2", "--steps", "2", "--warmup", "1", "--strategy", strategy]
-    p = subprocess.run(cmd, env=ENV, capture_output=True, text=True, timeout=400, cwd=ROOT)
+_TWO = [(s, 2) for s in ["keras", "custom:ring", "custom:direct", "sync", "async", "graph:1"]]
+_NODE = [(s, 8) for s in ["keras", "custom:direct", "custom:multiring", "sync", "async", "graph:3"]]
+
+
+@pytest.mark.parametrize("strategy,world", _TWO + _NODE)
+def test_bench_every_strategy_two_ranks_and_eight(strategy, world):
+    """The benchmark drives every strategy; the JSON proves that all ranks took part, shows the phases and reports
+    that the replicas agree after the run. World 8 is the launch the driver makes on a whole node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--device", "cpu",
+           "--model", "bert-tiny", "--batch", "2", "--steps", "2", "--warmup", "1", "--strategy", strategy,
+           "--comm-timeout-s", "120"]
+    p = subprocess.run(cmd, env=dict(ENV, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=400, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     r = json.loads(lines[0])
-    assert r["ranks_seen"] == 2 and r["n_gpus"] == 2 and r["comm_backend"] == "gloo"
+    assert r["ranks_seen"] == world and r["n_gpus"] == world and r["comm_backend"] == "gloo"
     assert r["config"]["strategy"] == strategy and r["config"]["model"] == "bert-tiny-mlm"
     assert r["unit"] == "sequences/sec" and r["value"] > 0
     assert r["replicas_agree"] is True

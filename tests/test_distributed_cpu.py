@@ -71,6 +71,32 @@ def test_all_reduce_algorithms_match_the_backend(algo, world):
     assert all(r[1] == res[0][1] for r in res)
 
 
+def _algo_all_body(comm, n):
+    """Every schedule in one process group (one spawn of 7-8 interpreters instead of five)."""
+    from distributed_tensorflow_amd.comm import algorithms as A
+    out = {}
+    for algo in ("direct", "ring", "multiring", "tree", "oneshot"):
+        torch.manual_seed(100 + comm.rank)
+        buf = torch.randn(n)
+        ref = buf.clone()
+        A.ALGORITHMS[algo](comm, buf)
+        comm.all_reduce(ref)
+        out[algo] = (float((buf - ref).abs().max()), buf[:64].tolist())
+    return out
+
+
+@pytest.mark.parametrize("world", [7, 8])
+def test_all_reduce_algorithms_at_the_node_size(world):
+    """World 8 is the node the framework is built for; 7 exercises the non-power-of-two tree and the odd
+    Walecki decomposition of the multi-ring schedule."""
+    n = 8 * world * 6 * 5 * 7
+    res = _run(_algo_all_body, world, n)
+    for algo in res[0]:
+        for r in res:
+            assert r[algo][0] < 1e-5, (algo, r[algo][0])
+        assert all(r[algo][1] == res[0][algo][1] for r in res), algo
+
+
 def _rs_ag_body(comm):
     from distributed_tensorflow_amd.comm import algorithms as A
     W = comm.world
@@ -158,6 +184,32 @@ def test_sync_strategies_equal_large_batch_training(kind):
         assert torch.allclose(a, b, rtol=1e-4, atol=2e-6), s.name
 
 
+def _strategy_all_body(comm, kinds, steps):
+    return {k: _strategy_body(comm, k, steps)[0] for k in kinds}
+
+
+@pytest.mark.parametrize("world", [7, 8])
+def test_sync_strategies_at_the_node_size(world):
+    """Every synchronous strategy at the world size of one node: replicas bit-identical, equal to one process on the
+    whole batch."""
+    kinds = ["keras", "custom:direct", "custom:ring", "custom:multiring", "custom:tree", "custom:oneshot", "sync"]
+    steps = 2
+    res = _run(_strategy_all_body, world, kinds, steps)
+    ref = _single_process_reference(world, steps)
+    from distributed_tensorflow_amd.engine.flat import FlatParams
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    for kind in kinds:
+        for r in res[1:]:
+            assert (r[kind] == res[0][kind]).all(), kind
+        got = torch.from_numpy(res[0][kind])
+        layout = FlatParams.from_module(reference_mlp(dropout=0.0), shard_ways=1 if kind == "keras" else world)
+        for s in layout.slots:
+            a = got[s.offset:s.offset + s.numel]
+            rs = ref.by_name[s.name]
+            b = ref.master[rs.offset:rs.offset + rs.numel]
+            assert torch.allclose(a, b, rtol=1e-4, atol=2e-6), (kind, s.name)
+
+
 def _sequential_body(comm, steps):
     from distributed_tensorflow_amd.engine.optimizer import Adam
     from distributed_tensorflow_amd.engine.replica import TrainConfig
@@ -231,6 +283,62 @@ def test_graph_strategy_gossip_keeps_replicas_close_and_finalize_reaches_consens
     assert all(d < 1e-6 for d, _, _ in full)
 
 
+def _graph_degrees_body(comm, degrees):
+    """Every degree in one process group; a degree without a regular graph must raise on every rank."""
+    from distributed_tensorflow_amd.engine.optimizer import SGD
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.models.mlp import reference_mlp
+    from distributed_tensorflow_amd.parallel import mirrored
+    out = {}
+    x, y, _, _ = _make_data(comm.world, comm.rank, per=8)
+    for d in degrees:
+        torch.manual_seed(0)
+        try:
+            st = mirrored.GraphStrategy(reference_mlp(dropout=0.0), comm, TrainConfig(), optimizer=SGD(0.05), degree=d)
+        except ValueError as e:
+            out[d] = "ValueError"
+            continue
+        for _ in range(2):
+            st.train_step(x, y)
+        dis = st.disagreement()
+        st.finalize()
+        out[d] = (dis, st.disagreement(), sorted(st.neighbours))
+    return out
+
+
+@pytest.mark.parametrize("world", [7, 8])
+def test_graph_strategy_runs_for_every_degree_at_the_node_size(world):
+    """`-d` from 1 to world - 1 (reference initializer.py:90-92 reserves the flag): every graph is undirected, so every
+    send has its receive and no degree can block; an odd degree on an odd number of nodes is refused up front."""
+    degrees = list(range(1, world))
+    res = _run(_graph_degrees_body, world, degrees)
+    for d in degrees:
+        if world % 2 == 1 and d % 2 == 1 and d < world - 1:
+            assert all(r[d] == "ValueError" for r in res), d
+            continue
+        for r, out in enumerate(res):
+            dis, after, nb = out[d]
+            assert len(nb) == d and r not in nb
+            assert all(r in res[j][d][2] for j in nb), (d, r, nb)       # undirected
+            assert after < 1e-6
+            assert dis < 0.05 if d < world - 1 else dis < 1e-6            # complete graph: exact averaging
+
+
+def test_circulant_graph_is_undirected_for_every_world_and_degree():
+    from distributed_tensorflow_amd.parallel.mirrored import circulant_neighbours, graph_is_undirected
+    for world in range(1, 17):
+        for d in range(0, world + 2):
+            if world % 2 == 1 and d % 2 == 1 and d < world - 1:
+                with pytest.raises(ValueError):
+                    circulant_neighbours(0, world, d)
+                continue
+            assert graph_is_undirected(world, d)
+            for r in range(world):
+                nb = circulant_neighbours(r, world, d)
+                assert len(nb) == len(set(nb)) == min(d, world - 1) and r not in nb
+    assert sorted(circulant_neighbours(0, 8, 3)) == [1, 4, 7]      # +-1 and the antipode
+
+
 def _async_body(comm, placement, steps):
     from distributed_tensorflow_amd.engine.optimizer import Adam
     from distributed_tensorflow_amd.engine.replica import TrainConfig
@@ -251,7 +359,7 @@ def _async_body(comm, placement, steps):
     return moved, st.flat.master[: st.flat.used].clone().numpy(), st.version, out["steps"], max(st.staleness_log or [0])
 
 
-@pytest.mark.parametrize("placement,world", [("colocated", 3), ("dedicated", 3)])
+@pytest.mark.parametrize("placement,world", [("colocated", 3), ("dedicated", 3), ("colocated", 8), ("dedicated", 8)])
 def test_async_ps_applies_every_gradient_and_replicas_end_equal(placement, world):
     steps = 4
     res = _run(_async_body, world, placement, steps)
