@@ -79,6 +79,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--algorithm", default="auto", help="custom strategy: auto|direct|ring|multiring|tree|oneshot on grouped send/recv, or "
                    "ipc|ipc-direct|ipc-fused|ipc-oneshot|ipc-ring|ipc-tree: kernels on HIP IPC mapped peer arenas (ipc-fused: one launch per bucket)")
     p.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
+    p.add_argument("--optimizer", choices=["adam", "sgd", "momentum"], default="adam",
+                   help="the optimizer object the reference's server.start(optimizer=...) accepts (default: Keras Adam)")
+    p.add_argument("--learning-rate", type=float, default=None, help="default: the optimizer's Keras default")
     p.add_argument("--port", type=int, default=6000,
                    help="parameter-server port (reference: 6000); 0 = one the operating system picks (single machine)")
     p.add_argument("--metrics", default=None, help="JSONL metrics path (%%r = rank)")
@@ -147,6 +150,17 @@ def _train_config(args, centralized: bool, shard_ways: int = 1):
                        verify_replicas=int(getattr(args, "verify_replicas", 0) or 0))
 
 
+def _optimizer_spec(args):
+    """The optimizer description handed to every strategy (reference centralized/server.py:42,52-55: an optional
+    optimizer object, Adam by default)."""
+    from ..engine.optimizer import resolve_spec
+    spec = resolve_spec(getattr(args, "optimizer", None) or "adam")
+    lr = getattr(args, "learning_rate", None)
+    if lr is not None:
+        spec.learning_rate = float(lr)
+    return spec
+
+
 # ----------------------------------------------------------------------------- rank bodies
 def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: str, port, queue) -> None:
     """One rank of a collective (RCCL / gloo) strategy."""
@@ -177,21 +191,24 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
         cfg = _train_config(args, centralized=kind in ("sync", "async"))
         torch.manual_seed(args.seed)          # the initial weights are a function of --seed
         model = model_fn()
+        opt = _optimizer_spec(args)
         if kind == "keras":
-            st = mirrored.MirroredStrategy(model, comm, cfg, metrics=metrics)
+            st = mirrored.MirroredStrategy(model, comm, cfg, optimizer=opt, metrics=metrics)
         elif kind == "custom":
-            st = mirrored.CustomAllReduceStrategy(model, comm, cfg, metrics=metrics, algorithm=args.algorithm)
+            st = mirrored.CustomAllReduceStrategy(model, comm, cfg, optimizer=opt, metrics=metrics,
+                                                  algorithm=args.algorithm)
         elif kind == "graph":
-            st = mirrored.GraphStrategy(model, comm, cfg, metrics=metrics, degree=args.degree)
+            st = mirrored.GraphStrategy(model, comm, cfg, optimizer=opt, metrics=metrics, degree=args.degree)
         elif kind == "sync":
-            st = ps.SyncPSStrategy(model, comm, cfg, metrics=metrics, apply=args.apply)
+            st = ps.SyncPSStrategy(model, comm, cfg, optimizer=opt, metrics=metrics, apply=args.apply)
         elif kind == "async":
-            st = ps.AsyncPSStrategy(model, comm, cfg, metrics=metrics, placement=args.placement)
+            st = ps.AsyncPSStrategy(model, comm, cfg, optimizer=opt, metrics=metrics, placement=args.placement)
         else:
             raise ValueError(kind)
         if getattr(args, "load_weights", None):
             st.replica.model.load_weights(args.load_weights)      # every rank reads the same file
             st.flat.refresh_shadow()
+            st.on_weights_loaded()
         wd_s = float(getattr(args, "watchdog_s", 0.0) or 0.0)
         if wd_s > 0:
             st.watchdog = Watchdog(wd_s, rank=rank, poll=getattr(comm, "async_error", None))
@@ -255,6 +272,31 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
         sys.exit(1)
 
 
+def _tcp_server_extras(args) -> dict:
+    """Persistence and time limits of the framed-TCP topology: the server owns the model, so it is the one that
+    imports / exports weights and writes / resumes checkpoints."""
+    t = float(getattr(args, "comm_timeout_s", 300.0) or 300.0)
+    return dict(load_weights=getattr(args, "load_weights", None), save_weights=getattr(args, "save_weights", None),
+                checkpoint_dir=getattr(args, "checkpoint_dir", None),
+                checkpoint_every=int(getattr(args, "checkpoint_every", 0) or 0),
+                resume=bool(getattr(args, "resume", False)), barrier_timeout=t, accept_timeout=max(t, 120.0),
+                optimizer=_explicit_optimizer(args))
+
+
+def _explicit_optimizer(args):
+    """None unless the command line names an optimizer or a learning rate: with None the TCP server keeps the
+    reference's default, one private Adam per connection under apply='sequential' (server.py:52-55,170)."""
+    if getattr(args, "learning_rate", None) is None and (getattr(args, "optimizer", None) or "adam") == "adam":
+        return None
+    return _optimizer_spec(args)
+
+
+def _tcp_worker_extras(args) -> dict:
+    return dict(checkpoint_dir=getattr(args, "checkpoint_dir", None), resume=bool(getattr(args, "resume", False)),
+                watchdog_s=float(getattr(args, "watchdog_s", 0.0) or 0.0),
+                io_timeout=float(getattr(args, "comm_timeout_s", 300.0) or 300.0))
+
+
 def _tcp_server(args, model_fn, dataset_fn, queue, ready, cell=None) -> None:
     try:
         from ..parallel import ps_tcp
@@ -262,7 +304,8 @@ def _tcp_server(args, model_fn, dataset_fn, queue, ready, cell=None) -> None:
         ps_tcp.start(args.centralized_strategy, model_fn, dataset_fn, args.n_nodes, cpu_affinity=args.cpu_affinity,
                      server_address=args.server_address, port=args.port, apply=args.apply, device=dev,
                      cfg=_train_config(args, True), result_queue=queue, metrics_path=args.metrics, ready_event=ready,
-                     port_cell=cell, supervisor_address=getattr(args, "supervisor_address", None))
+                     port_cell=cell, supervisor_address=getattr(args, "supervisor_address", None),
+                     **_tcp_server_extras(args))
     except BaseException:
         traceback.print_exc()
         sys.exit(1)
@@ -276,7 +319,7 @@ def _tcp_worker(index: int, args, model_fn, dataset_fn, queue, cell=None) -> Non
                      n_nodes=args.n_nodes, cpu_affinity=args.cpu_affinity, server_address=args.server_address,
                      port=args.port, device=dev, cfg=_train_config(args, True), max_steps=args.max_steps,
                      result_queue=queue, fault_hook=_fault_hook(args.fault_inject), metrics_path=args.metrics,
-                     port_cell=cell)
+                     port_cell=cell, **_tcp_worker_extras(args))
     except BaseException:
         traceback.print_exc()
         sys.exit(1)
@@ -366,7 +409,8 @@ def run(args, model_fn: Callable, dataset_fn: Callable) -> dict:
             res = ps_tcp.start(cs, model_fn, dataset_fn, args.n_nodes, cpu_affinity=args.cpu_affinity,
                                server_address=args.server_address, port=args.port, apply=args.apply,
                                device=_device_for(0, args.device), cfg=_train_config(args, True),
-                               metrics_path=args.metrics)
+                               metrics_path=args.metrics, supervisor_address=getattr(args, "supervisor_address", None),
+                               **_tcp_server_extras(args))
             res.pop("weights", None)
             return {"ok": True, "server": res}
         if args.task_type == "worker" and args.task_index is not None:
@@ -375,7 +419,8 @@ def run(args, model_fn: Callable, dataset_fn: Callable) -> dict:
                                num_epochs=args.epochs, n_nodes=args.n_nodes or 0, cpu_affinity=args.cpu_affinity,
                                server_address=args.server_address, port=args.port,
                                device=_device_for(args.task_index, args.device), cfg=_train_config(args, True),
-                               max_steps=args.max_steps, metrics_path=args.metrics)
+                               max_steps=args.max_steps, metrics_path=args.metrics,
+                               fault_hook=_fault_hook(args.fault_inject), **_tcp_worker_extras(args))
             return {"ok": True, f"worker{args.task_index}": res}
         raise ValueError("Invalid task type: use -tt server, or -tt worker with -ti INDEX")
 

@@ -13,9 +13,10 @@ Schedules (``plan``):
 ``oneshot``  every rank sums the whole buffer of all peers into scratch (one hop; small buffers)
 ``ring``     the classic 2(W-1)-step ring, kept for comparison: it is bound by ONE link
 ``tree``     binomial reduce to rank 0 + binomial broadcast: log2(W) hops for tiny buffers
-``fused``    the ``direct`` schedule as ONE kernel launch per rank: a small resident grid runs entry barrier,
-             reduce-scatter, barrier, all-gather and exit barrier itself (grid counters inside the device, growing
-             sequence numbers in the peers' flag arrays), instead of five launches per bucket
+``fused``    the ``direct`` schedule as ONE kernel launch per rank: a resident grid sized from the bucket runs entry
+             barrier, reduce-scatter, barrier, all-gather and exit barrier itself (grid counters inside the device,
+             growing sequence numbers in the peers' flag arrays), instead of five launches per bucket; the reduced
+             shard is stored through the caches, so no barrier writes a cache back
 
 The schedule is pure Python data, so it is verified on the CPU by an emulator
 (:func:`emulate`) that also detects read/write races inside a phase; the kernels are verified
@@ -114,6 +115,22 @@ def pick_algorithm(nbytes: int, world: int) -> str:
     return "direct"
 
 
+def fused_grid(nbytes: int, world: int, cap: int = 256, max_threads: int = 256) -> tuple[int, int]:
+    """(blocks, threads per block) of the single-launch all-reduce for a bucket of ``nbytes``: 32 blocks of 256
+    threads up to 2 MiB (latency bound: three barriers, each as slow as its slowest block), then one more block per
+    128 KiB that a rank moves (it reads ``world`` shards and pulls ``world - 1``), up to ``cap`` -- the CU budget
+    the strategy grants a collective that runs under the backward pass (at most one block per CU: every block must be
+    able to become resident) -- and from there wider blocks, up to ``max_threads``. 64 x 256 threads keep seven xGMI
+    links busy; wide blocks only pay where the transfer is bound by device memory (ranks sharing one GPU)."""
+    cap = max(1, min(int(cap), 256))
+    want = -(-2 * nbytes // (128 << 10))
+    blocks = max(min(32, cap), min(cap, want))
+    threads = 256
+    while threads < min(int(max_threads), 1024) and blocks * (threads // 256) < want:
+        threads *= 2
+    return blocks, threads
+
+
 def emulate(algorithm: str, bufs: list, scale: float = 1.0) -> None:
     """Runs the schedule on host arrays (numpy or CPU tensors), in place, phase by phase, and
     raises if a phase reads a region that another rank writes in the same phase."""
@@ -168,11 +185,10 @@ def _k():
         lib.dtf_p2p_reduce.argtypes = [ctypes.POINTER(vp), i, vp, ll, ll, i, ctypes.c_float, i, vp]
         lib.dtf_p2p_gather.argtypes = [ctypes.POINTER(vp), i, i, vp, ll, ll, i, vp]
         lib.dtf_p2p_barrier.argtypes = [ctypes.POINTER(vp), i, i, ctypes.c_uint, i, vp, vp]
-        lib.dtf_p2p_allreduce_fused.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), i, i, vp, vp, ll, ll, i,
-                                                ctypes.c_float, ctypes.c_uint, ctypes.c_uint, i, i, vp]
+        lib.dtf_p2p_allreduce_fused.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), i, i, vp, ll, ll, i,
+                                                ctypes.c_float, ctypes.c_uint, i, i, i, vp]
         lib.dtf_p2p_allreduce_fused_virtual.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), i, ctypes.POINTER(vp),
-                                                        ctypes.POINTER(vp), ll, ll, i, ctypes.c_float, ctypes.c_uint,
-                                                        ctypes.c_uint, i, i, vp]
+                                                        ll, ll, i, ctypes.c_float, ctypes.c_uint, i, i, i, vp]
         lib._p2p_declared = True
     return lib
 
@@ -237,10 +253,11 @@ class LocalPeers:
         self.world = len(bufs)
         self.scratch = [torch.empty_like(b) for b in bufs]
 
-    def _fused(self, scale: float, start: int, n: int, blocks: int = 8, budget_ms: int = 5000) -> None:
+    def _fused(self, scale: float, start: int, n: int, blocks: int | None = None, budget_ms: int = 5000) -> None:
         """The single-launch all-reduce with the W virtual ranks as the rows of ONE grid, so that they are resident
         together by construction; each row runs the code of a real rank against its own counters, flag array and
-        status word and synchronises with the others exactly as W processes would."""
+        status word and synchronises with the others exactly as W processes would. ``blocks`` (per rank; default:
+        sized from the region, W x blocks <= 256)."""
         b0 = self.bufs[0]
         dev = b0.device
         if not hasattr(self, "_fz"):
@@ -250,19 +267,18 @@ class LocalPeers:
                 p = ctypes.c_void_p()
                 _lib.check(rt.dtf_ipc_alloc_flags(4 * 64, ctypes.byref(p)), "flag allocation")
                 flags.append(p.value)
-            self._fz = dict(flags=flags, local=[torch.zeros(2, dtype=torch.int32, device=dev) for _ in self.bufs],
-                            status=[torch.zeros(1, dtype=torch.int32, device=dev) for _ in self.bufs],
-                            seq=0, arrive=0, blocks=blocks)
+            self._fz = dict(flags=flags, status=[torch.zeros(1, dtype=torch.int32, device=dev) for _ in self.bufs],
+                            arrive=0)
         z = self._fz
-        if blocks != z["blocks"]:
-            raise ValueError("the fused all-reduce keeps one grid size per group")
+        threads = 256
+        if blocks is None:
+            blocks, threads = fused_grid(n * b0.element_size(), self.world, cap=256 // self.world, max_threads=1024)
         rc = _k().dtf_p2p_allreduce_fused_virtual(
             _ptr_array([b.data_ptr() for b in self.bufs]), _ptr_array(z["flags"]), self.world,
-            _ptr_array([t.data_ptr() for t in z["local"]]), _ptr_array([t.data_ptr() for t in z["status"]]), start, n,
-            _lib.dtype_code(b0.dtype), scale, z["seq"], z["arrive"], blocks, budget_ms, _lib.stream_ptr(dev))
+            _ptr_array([t.data_ptr() for t in z["status"]]), start, n,
+            _lib.dtype_code(b0.dtype), scale, z["arrive"], blocks, threads, budget_ms, _lib.stream_ptr(dev))
         _lib.check(rc, "p2p allreduce_fused (virtual ranks)")
-        z["seq"] += 3
-        z["arrive"] += 3 * blocks
+        z["arrive"] = (z["arrive"] + 3 * blocks) & 0xFFFFFFFF
 
     def fused_status(self) -> list[int]:
         return [int(t.item()) for t in self._fz["status"]]
@@ -288,7 +304,8 @@ class PeerGroup:
     """One rank per process. ``comm`` is only used to exchange IPC handles (``gather_objects``:
     callable returning the list of every rank's object; default ``all_gather_object``)."""
 
-    def __init__(self, comm, gather_objects=None, barrier_budget_ms: int = 20000, max_blocks: int = 0):
+    def __init__(self, comm, gather_objects=None, barrier_budget_ms: int = 20000, max_blocks: int = 0,
+                 fused_threads: int = 256):
         self.comm = comm
         self.rank, self.world, self.device = comm.rank, comm.world, comm.device
         self._gather = gather_objects or self._default_gather
@@ -303,7 +320,10 @@ class PeerGroup:
         self._flag_ptrs = self._map(self._flags_own)
         # the single-launch all-reduce counts in words of its own (16 words into each rank's flag array)
         self._fused_flag_ptrs = [q + 64 for q in self._flag_ptrs]
-        self.fused_blocks = max_blocks if 0 < max_blocks <= 64 else 32     # resident at once, leaves CUs to backward
+        # CU budget of the single-launch all-reduce (its grid grows with the bucket up to this many blocks; the rest
+        # of the device stays with the backward pass)
+        self.fused_blocks = max_blocks if 0 < max_blocks <= 256 else 64
+        self.fused_threads = fused_threads      # widest block of that grid (1024 only pays on a shared GPU)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._registered: dict[int, tuple[list[int], torch.Tensor]] = {}
 
@@ -349,7 +369,9 @@ class PeerGroup:
     def _raise_if(self, s: int) -> None:
         if s:
             missing = [j for j in range(self.world) if s >> j & 1]
-            raise RuntimeError(f"peer-pointer barrier timed out waiting for ranks {missing}: the buffers reduced "
+            own = " (this rank's own grid among them: some of its blocks were not resident in time)" \
+                if self.rank in missing else ""
+            raise RuntimeError(f"peer-pointer barrier timed out waiting for ranks {missing}{own}: the buffers reduced "
                                "since then hold partial sums")
 
     def check(self) -> None:
@@ -384,16 +406,16 @@ class PeerGroup:
         if algorithm == "auto":
             algorithm = pick_algorithm(t.numel() * esz, self.world)
         if algorithm == "fused":
-            if not hasattr(self, "_fused_local"):
-                self._fused_local = torch.zeros(2, dtype=torch.int32, device=self.device)
-                self._fused_seq = self._fused_arrive = 0
+            if not hasattr(self, "_fused_arrive"):
+                self._fused_arrive = 0
+            blocks, threads = fused_grid(t.numel() * esz, self.world, cap=self.fused_blocks,
+                                         max_threads=self.fused_threads)
             rc = _k().dtf_p2p_allreduce_fused(_ptr_array(ptrs), _ptr_array(self._fused_flag_ptrs), self.world, self.rank,
-                                              self._fused_local.data_ptr(), self.status.data_ptr(), start, t.numel(),
-                                              _lib.dtype_code(t.dtype), scale, self._fused_seq, self._fused_arrive,
-                                              self.fused_blocks, self._budget, _lib.stream_ptr(self.device))
+                                              self.status.data_ptr(), start, t.numel(),
+                                              _lib.dtype_code(t.dtype), scale, self._fused_arrive,
+                                              blocks, threads, self._budget, _lib.stream_ptr(self.device))
             _lib.check(rc, "p2p allreduce_fused")
-            self._fused_seq += 3
-            self._fused_arrive += 3 * self.fused_blocks
+            self._fused_arrive = (self._fused_arrive + 3 * blocks) & 0xFFFFFFFF
             return algorithm
         phases = plan(algorithm, self.rank, self.world, t.numel(), esz, scale)
         if self.world > 1:

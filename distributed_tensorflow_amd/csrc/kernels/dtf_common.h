@@ -63,6 +63,14 @@ __device__ __forceinline__ void store4_bf16(unsigned short* p, float a, float b,
   *reinterpret_cast<u32x2_t*>(p) = v;
 }
 
+// 16-byte store that goes through the caches to memory (system scope): the bytes are where another GPU that maps
+// this buffer reads them once the storing wave's `s_waitcnt vmcnt(0)` has returned, with no cache write-back
+// (a release fence writes back the whole L2 of the XCD). Costs the same as a plain 16-byte store.
+__device__ __forceinline__ void store16_through(void* p, u32x4_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

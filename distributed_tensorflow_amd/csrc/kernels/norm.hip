@@ -689,7 +689,11 @@ __global__ __launch_bounds__(kBlock) void bn_relu_maxpool_fwd_kernel(const unsig
           const unsigned code = 255u - (unsigned)(kh * K + kw);
 #pragma unroll
           for (int k = 0; k < 8; k += 2) {
-            const float lo = fmaxf(fmaf(v[k], sa[k], sb[k]), 0.f), hi = fmaxf(fmaf(v[k + 1], sa[k + 1], sb[k + 1]), 0.f);
+            // ReLU as a signed-integer maximum of the float's bits: negative values (sign bit set) become 0 and a
+            // NaN keeps its bits, so it wins the key comparison below and reaches the output like in the unfused
+            // norm + ReLU + pool (a float maximum would turn it into 0); one instruction either way
+            const float lo = __int_as_float(max(__float_as_int(fmaf(v[k], sa[k], sb[k])), 0));
+            const float hi = __int_as_float(max(__float_as_int(fmaf(v[k + 1], sa[k + 1], sb[k + 1])), 0));
             const unsigned pk = pack_bf16x2(lo, hi) & 0x7fff7fffu;       // (a negative zero must not outrank anything)
             key[k] = max(key[k], (pk << 16) | code);
             key[k + 1] = max(key[k + 1], (pk & 0xffff0000u) | code);

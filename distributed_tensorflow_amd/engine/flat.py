@@ -15,6 +15,15 @@ The layout is in REVERSE parameter order: backward produces the last layer's
 gradients first, so bucket 0 (the lowest addresses) is the first to complete
 and the first to be communicated.
 
+``split_dtypes`` (the sharded parameter server's layout) places the bf16
+parameters first and the fp32 ones (norm scales and offsets, biases kept in
+fp32) after them, each group in reverse parameter order, and no bucket crosses
+the boundary ``split``. An fp32 parameter IS its master copy, so that region
+stays whole on every rank; below ``split`` the fp32 master is a copy that only
+the optimizer reads, and :meth:`FlatParams.shard_master` cuts it down to the
+ranges a rank owns (1/W of it): 4 of the 6 bytes a bf16 parameter costs in
+arenas become 4/W.
+
 The reference keeps weights as a Python list of per-variable arrays that is
 pickled on every push and pull (reference centralized/server.py:96,101,104;
 client.py:85-90); the arenas make that list a set of views and the wire format
@@ -62,9 +71,10 @@ class FlatParams:
     """Re-homes the trainable parameters of ``module`` into flat arenas."""
 
     def __init__(self, named_params: Iterable[tuple[str, torch.nn.Parameter]], grad_dtype: torch.dtype = torch.float32,
-                 shard_ways: int = 1):
+                 shard_ways: int = 1, split_dtypes: bool = False):
         """``shard_ways``: every slot is padded to ``ALIGN * shard_ways`` elements so that any
-        run of whole slots (a bucket) splits into ``shard_ways`` equal, aligned shards."""
+        run of whole slots (a bucket) splits into ``shard_ways`` equal, aligned shards.
+        ``split_dtypes``: bf16 parameters first, fp32 parameters after them (see the module text)."""
         named = [(n, p) for n, p in named_params if p.requires_grad]
         if not named:
             raise ValueError("model has no trainable parameters")
@@ -79,11 +89,22 @@ class FlatParams:
         self.align = ALIGN * self.shard_ways
         self.slots: list[Slot] = []
         off = 0
-        for n, p in reversed(named):
+        order = list(reversed(named))
+        self.split = None               # first element of the fp32 region (split layout only)
+        if split_dtypes:
+            order = [np_ for np_ in order if np_[1].dtype == torch.bfloat16] + \
+                    [np_ for np_ in order if np_[1].dtype != torch.bfloat16]
+        for n, p in order:
+            if split_dtypes and self.split is None and p.dtype != torch.bfloat16:
+                self.split = off
             self.slots.append(Slot(n, p, off, p.numel(), p.shape, p.dtype, _dense_strides(p)))
             off += _round_up(p.numel(), self.align)
+        if split_dtypes and self.split is None:
+            self.split = off
         self.used = off
         self.total = off
+        self.master_base = 0            # arena coordinate of master[0]; > 0 once shard_master() has run
+        self.master_shards = None       # (ranges, compact fp32 tensor) of the owned part below ``split``
         self.has_bf16 = any(s.dtype == torch.bfloat16 for s in self.slots)
         self.master = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device) if self.has_bf16 else None
@@ -115,7 +136,64 @@ class FlatParams:
         return self._view(self.grad, s)
 
     def master_view(self, s: Slot) -> torch.Tensor:
-        return self._view(self.master, s)
+        if s.offset < self.master_base:
+            raise ValueError(f"the fp32 master of {s.name} is sharded across the ranks (shard_master)")
+        return self.master.as_strided(tuple(s.shape), s.stride, s.offset - self.master_base)
+
+    def m32(self, a: int, b: int) -> torch.Tensor:
+        """``master`` in arena coordinates: the replicated fp32 region, or -- below ``split`` after
+        :meth:`shard_master` -- the compact storage of a range this rank owns."""
+        if a >= self.master_base:
+            return self.master[a - self.master_base:b - self.master_base]
+        ranges, store = self.master_shards
+        base = 0
+        for ra, rb in ranges:
+            if ra <= a and b <= rb:
+                return store[base + a - ra:base + b - ra]
+            base += rb - ra
+        raise ValueError(f"range [{a}, {b}) of the fp32 master is not owned by this rank")
+
+    @torch.no_grad()
+    def shard_master(self, ranges: Sequence[tuple[int, int]]) -> None:
+        """Keeps, of the fp32 master below ``split`` (the copies of bf16 parameters), only ``ranges`` -- the
+        shards this rank owns as a parameter server -- in compact storage, and releases the rest. The fp32
+        region at and above ``split`` stays whole (those parameters are views of it). Afterwards ``master`` is
+        that region only (``master_base == split``); use :meth:`m32` for arena coordinates."""
+        if self.split is None:
+            raise ValueError("shard_master needs the split layout (FlatParams(split_dtypes=True))")
+        if self.master_base:
+            raise ValueError("the master arena is already sharded")
+        own = [(int(a), int(b)) for a, b in ranges if b > a and a < self.split]
+        if any(b > self.split for _, b in own):
+            raise ValueError("an owned range crosses the boundary between bf16 and fp32 parameters")
+        store = torch.cat([self.master[a:b] for a, b in own]) if own else self.master.new_empty(0)
+        hi = self.master[self.split:].clone()
+        for s in self.slots:
+            if s.offset >= self.split:
+                s.param.data = hi.as_strided(tuple(s.shape), s.stride, s.offset - self.split)
+            elif hasattr(s.param, "_dtf_master"):
+                del s.param._dtf_master      # no full-precision copy of this parameter on this rank any more
+        self.master = hi
+        self.master_base = self.split
+        self.master_shards = (own, store)
+
+    @torch.no_grad()
+    def write_master(self, full: torch.Tensor) -> None:
+        """Loads ``full`` (fp32, the whole index space) into whatever part of the master this rank holds, and the
+        bf16 working copies."""
+        full = full.to(self.device)
+        if not self.master_base:
+            self.master[: self.used].copy_(full[: self.used])
+            self.refresh_shadow()
+            return
+        self.master.copy_(full[self.master_base:self.total])
+        ranges, store = self.master_shards
+        base = 0
+        for a, b in ranges:
+            store[base:base + b - a].copy_(full[a:b])
+            base += b - a
+        from ..ops import bucket as _b
+        _b.scale_cast(full[: self.master_base].contiguous(), self.shadow[: self.master_base])
 
     def bind_grads_as_views(self) -> None:
         """Point every ``param.grad`` at its slice of the grad arena (autograd then
@@ -132,7 +210,9 @@ class FlatParams:
     @torch.no_grad()
     def refresh_shadow(self) -> None:
         """shadow <- master (after an external write to ``master``, e.g. a pull or a load)."""
-        if self.shadow is not None:
+        if self.shadow is not None and not self.master_base:
+            # (with a sharded master the bf16 arena is itself the replicated working copy: the owners write their
+            # shards of it in the optimizer kernel and the pull all-gathers it)
             from ..ops import bucket as _b
             _b.scale_cast(self.master, self.shadow)
 
@@ -143,6 +223,8 @@ class FlatParams:
 
     def nbytes(self) -> int:
         n = self.master.numel() * 4 + self.grad.numel() * self.grad.element_size()
+        if self.master_shards is not None:
+            n += self.master_shards[1].numel() * 4
         if self.shadow is not None:
             n += self.shadow.numel() * 2
         return n
@@ -150,6 +232,10 @@ class FlatParams:
     def checksum(self) -> torch.Tensor:
         """fp64 sum and sum of squares of ``master`` -- compared across ranks in debug mode
         to detect replica divergence."""
+        if self.master_base:
+            # replicated state: the bf16 working copy below the boundary, the fp32 parameters above it
+            lo, hi = self.shadow[: self.master_base].double(), self.master.double()
+            return torch.stack([lo.sum() + hi.sum(), (lo * lo).sum() + (hi * hi).sum()])
         m = self.master[: self.used].double()
         return torch.stack([m.sum(), (m * m).sum()])
 
@@ -194,13 +280,15 @@ class BucketPlanner:
         buckets: list[Bucket] = []
         cur: list[Slot] = []
         start = 0
+        split = getattr(flat, "split", None)
         for s in flat.slots:
             end = s.offset + _round_up(s.numel, flat.align)
-            if cur and end - start > limit:
+            if cur and (end - start > limit or s.offset == split):     # no bucket holds both kinds of parameter
                 buckets.append(Bucket(len(buckets), start, s.offset, tuple(cur)))
                 start, cur, limit = s.offset, [], cap
             cur.append(s)
-        if last_cap_bytes and len(cur) > 1 and flat.total - start > last_cap_bytes // esize:
+        if last_cap_bytes and len(cur) > 1 and flat.total - start > last_cap_bytes // esize \
+                and not (split is not None and start < split < flat.total):
             # the longest run of trailing slots that fits the small cap (at least one slot) becomes its own bucket
             cut = len(cur) - 1
             while cut > 1 and flat.total - cur[cut - 1].offset <= last_cap_bytes // esize:

@@ -104,21 +104,24 @@ class FlatOptimizer:
 
     @torch.no_grad()
     def step(self, ranges: Sequence[tuple[int, int]] | None = None, grad: torch.Tensor | None = None,
-             params=None) -> None:
+             params=None, tick: bool = True) -> None:
         """One optimizer step over ``ranges`` (default: everything owned). ``grad`` overrides the
         arena the gradients are read from (same indexing as ``flat.grad``). ``params`` overrides the fp32
         arena that is updated (same indexing as ``flat.master``; the bf16 shadow is then left alone): a
-        parameter-server owner keeps its authoritative shard apart from the replica's working copy."""
+        parameter-server owner keeps its authoritative shard apart from the replica's working copy.
+        ``tick=False``: a further call of the SAME optimizer step (one call per bucket): the step counter of the
+        bias correction does not advance."""
         f = self.flat
         g_arena = f.grad if grad is None else grad
-        self.hyper.tick()
-        self.steps += 1
+        if tick:
+            self.hyper.tick()
+            self.steps += 1
         for a, b in (self.ranges if ranges is None else ranges):
             if b <= a:
                 continue
             o = self._locate(a, b)
             n = b - a
-            p = f.master[a:b] if params is None else params[a:b]
+            p = f.m32(a, b) if params is None else params[a:b]
             g = g_arena[a:b]
             sh = f.shadow[a:b] if (f.shadow is not None and params is None) else None
             if self.spec.kind == "adam":

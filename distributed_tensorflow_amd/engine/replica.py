@@ -39,6 +39,7 @@ class TrainConfig:
     first_bucket_bytes: int | None = 8 << 20
     last_bucket_bytes: int | None = 4 << 20   # the last bucket's collective is exposed: keep it small
     shard_ways: int = 1
+    split_dtypes: bool = False            # arena layout: bf16 parameters first, fp32 after them (sharded parameter server)
     seed: int = 0
     graph: bool = False                   # capture the whole train step into a hipGraph (GPU, static shapes)
     verify_replicas: int = 0              # debug: compare the master-weight checksum across ranks every N steps
@@ -62,7 +63,8 @@ class Replica:
         self.model: Model = as_model(model).to(self.device)
         if self.cfg.param_dtype is not None and self.cfg.param_dtype != torch.float32:
             _cast_params(self.model, self.cfg.param_dtype, self.cfg.keep_fp32)
-        self.flat = FlatParams.from_module(self.model, grad_dtype=self.cfg.grad_dtype, shard_ways=self.cfg.shard_ways)
+        self.flat = FlatParams.from_module(self.model, grad_dtype=self.cfg.grad_dtype, shard_ways=self.cfg.shard_ways,
+                                           split_dtypes=self.cfg.split_dtypes)
         self.planner = BucketPlanner(self.flat, self.cfg.bucket_bytes, self.cfg.first_bucket_bytes,
                                      self.cfg.last_bucket_bytes)
         self.reducer = GradReducer(self.flat, self.planner)

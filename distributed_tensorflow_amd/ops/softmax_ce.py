@@ -29,7 +29,17 @@ def _label_code(y: torch.Tensor) -> int:
 
 
 def _row_padded(t: torch.Tensor) -> bool:
-    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.shape[0] > 0
+    """Rows that are read in place: contiguous, or padded to the next multiple of 16 bytes in a 16-byte aligned
+    buffer (the layout ``ops.dense.linear`` gives logits whose width is not a multiple of 8). Any other view -- a
+    column slice, rows of a much wider matrix -- is copied: backward allocates its gradient with the same row
+    stride and needs the same alignment as the input."""
+    if t.dim() != 2 or t.stride(1) != 1 or t.shape[0] <= 0:
+        return False
+    C, ld = t.shape[1], t.stride(0)
+    if ld == C:
+        return True
+    per16 = 16 // t.element_size()
+    return t.data_ptr() % 16 == 0 and ld == -(-C // per16) * per16
 
 
 def _fwd(logits: torch.Tensor, labels: torch.Tensor, want_correct: bool):

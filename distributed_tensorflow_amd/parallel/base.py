@@ -103,6 +103,10 @@ class Strategy:
                 f"step {step}: master weights differ across ranks (checksum max {hi.tolist()} != min {lo.tolist()}; "
                 f"this rank {c.tolist()})")
 
+    def on_weights_loaded(self) -> None:
+        """Called after ``flat.master`` has been rewritten from outside (weight import, checkpoint resume): a
+        strategy that keeps parameter state apart from the replica's arena copies it from there."""
+
     def finalize(self) -> None:
         """Brings every replica to the final model (no-op for strategies whose replicas agree)."""
 

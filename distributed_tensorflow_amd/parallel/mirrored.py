@@ -119,6 +119,13 @@ class CustomAllReduceStrategy(Strategy):
             self._peers.check_async()     # a barrier that timed out means partial sums: stop, do not train on
         return loss
 
+    def save_checkpoint(self, directory: str, step: int) -> None:
+        """A barrier that timed out leaves partial sums in the gradients already applied: look at the status word
+        itself (a host wait, once per checkpoint) before anything is written, so that no checkpoint can hold them."""
+        if self._peers is not None:
+            self._peers.check()
+        super().save_checkpoint(directory, step)
+
     def finalize(self) -> None:
         if self._peers is not None:
             self._peers.check()

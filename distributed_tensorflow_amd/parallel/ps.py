@@ -412,6 +412,18 @@ class AsyncPSStrategy(Strategy):
             w_.wait()
         f.refresh_shadow()
 
+    def on_weights_loaded(self) -> None:
+        """The authoritative shard follows an import / resume that rewrote the replica's arena; otherwise the
+        first apply would continue from the weights the server was constructed with."""
+        if self.ps_master is not None:
+            a, e = self.shard_of[self.comm.rank]
+            if self._apply_stream is not None:
+                self._apply_stream.wait_stream(torch.cuda.current_stream(self.comm.device))
+            with self.lock, self._stream_ctx():
+                self.ps_master.copy_(self.flat.master[a:e])
+            if self._apply_stream is not None:
+                torch.cuda.current_stream(self.comm.device).wait_stream(self._apply_stream)
+
     def finalize(self) -> None:
         r = self.comm.rank
         if self.is_worker:
@@ -452,9 +464,7 @@ class AsyncPSStrategy(Strategy):
         written at the end (the state of an asynchronous run in flight is not a single point in time)."""
         if resume:
             self.try_resume(checkpoint_dir)
-            if self.ps_master is not None:
-                a, e = self.shard_of[self.comm.rank]
-                self.ps_master.copy_(self.flat.master[a:e])
+            self.on_weights_loaded()
         it_count, last = 0, None
         if self.is_worker:
             n_local = dataset.num_batches()

@@ -25,7 +25,10 @@ Differences from the reference, all deliberate:
   * barriers have a timeout and are aborted when a connection drops, so a dead worker ends
     the job with an error instead of hanging it (server.py:132-134 keeps looping);
   * the server replies with trainable parameters only; buffers such as batch-norm statistics
-    stay local to each worker (server.py:96,101 overwrites them).
+    stay local to each worker (server.py:96,101 overwrites them);
+  * the server, which owns the model, also owns its persistence: it imports / exports the Keras-ordered
+    weight list and writes and resumes checkpoints (weights, optimizer state, per-worker step counts); a
+    worker adds its own random-number state and, on resume, skips the batches its completed steps consumed.
 """
 from __future__ import annotations
 
@@ -86,6 +89,13 @@ class _ServerState:
         self.staleness: list[int] = []
         self.step_latency: list[float] = []
         self.errors: list[BaseException] = []
+        self.steps_by_worker: dict[int, int] = {}      # worker index -> steps the server has applied for it
+        self.worker_opts: dict[int, FlatOptimizer] = {}   # per-worker optimizer states (apply='sequential')
+        self.checkpoint_dir: str | None = None
+        self.checkpoint_every = 0
+        self.resumed_from: dict[int, int] = {}
+        self._pending_opt_state: dict[int, dict] = {}
+        self.checkpoints_written = 0
 
     # barrier actions: run by exactly one thread while the others are still blocked
     def on_all_started(self):
@@ -98,6 +108,70 @@ class _ServerState:
             self.sum_grad.zero_()
             self.version += 1
         self.snapshot = self.flat.master.detach().cpu().clone()
+        self.rounds = getattr(self, "rounds", 0) + 1
+        if self.checkpoint_dir and self.checkpoint_every and self.rounds % self.checkpoint_every == 0:
+            self.save_checkpoint()
+
+    # ------------------------------------------------------------ persistence (the server owns the model)
+    def save_checkpoint(self) -> bool:
+        """Weights, optimizer state(s), version and per-worker step counts, written atomically. The caller is the only
+        thread touching the model (the barrier action, a holder of ``lock``, or the main thread after the join)."""
+        from ..utils.checkpoint import _atomic_save
+        os.makedirs(self.checkpoint_dir, exist_ok=True)
+        flat = self.flat
+        slots = {s.name: {"offset": s.offset, "numel": s.numel, "shape": list(s.shape)} for s in flat.slots}
+        opts = {"shared": self.shared_opt.state_dict() if self.shared_opt is not None else None,
+                "per_worker": {int(k): o.state_dict() for k, o in self.worker_opts.items()}}
+        _atomic_save({"master": flat.master.detach().cpu().clone(), "slots": slots, "optimizers": opts,
+                      "version": int(self.version), "rounds": int(getattr(self, "rounds", 0)),
+                      "steps_by_worker": {int(k): int(v) for k, v in self.steps_by_worker.items()},
+                      "sync_mode": self.sync_mode, "apply": self.apply}, os.path.join(self.checkpoint_dir, "ps_server.pt"))
+        self.checkpoints_written += 1
+        return True
+
+    def load_checkpoint(self) -> bool:
+        path = os.path.join(self.checkpoint_dir or "", "ps_server.pt")
+        if not self.checkpoint_dir or not os.path.exists(path):
+            return False
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        flat = self.flat
+        for s in flat.slots:
+            src = ck["slots"][s.name]
+            if src["numel"] != s.numel or list(src["shape"]) != list(s.shape):
+                raise ValueError(f"checkpoint tensor {s.name} has shape {src['shape']}, model expects {list(s.shape)}")
+            flat.master[s.offset:s.offset + s.numel].copy_(ck["master"][src["offset"]:src["offset"] + s.numel])
+        flat.refresh_shadow()
+        if self.shared_opt is not None and ck["optimizers"]["shared"] is not None:
+            self.shared_opt.load_state_dict(ck["optimizers"]["shared"])
+        self._pending_opt_state = {int(k): v for k, v in ck["optimizers"]["per_worker"].items()}
+        self.version = int(ck["version"])
+        self.rounds = int(ck.get("rounds", 0))
+        self.steps_by_worker = {int(k): int(v) for k, v in ck["steps_by_worker"].items()}
+        self.resumed_from = dict(self.steps_by_worker)
+        self.snapshot = flat.master.detach().cpu().clone()
+        return True
+
+    def optimizer_for(self, index: int) -> FlatOptimizer:
+        """The optimizer state that applies worker ``index``'s gradients: the shared one, or that worker's own
+        (the reference creates one Adam per connection thread, server.py:52-55)."""
+        if self.shared_opt is not None:
+            return self.shared_opt
+        with self.lock:
+            o = self.worker_opts.get(index)
+            if o is None:
+                o = FlatOptimizer(self.flat, self.optimizer_spec)
+                sd = self._pending_opt_state.pop(index, None)
+                if sd is not None:
+                    o.load_state_dict(sd)
+                self.worker_opts[index] = o
+        return o
+
+    def count_step(self, index: int) -> None:
+        """Under ``lock``: one more gradient of worker ``index`` applied; asynchronous mode checkpoints by count."""
+        self.steps_by_worker[index] = self.steps_by_worker.get(index, 0) + 1
+        if (self.sync_mode == "async" and self.checkpoint_dir and self.checkpoint_every
+                and sum(self.steps_by_worker.values()) % (self.checkpoint_every * self.n) == 0):
+            self.save_checkpoint()
 
     def worker_ended(self):
         with self.lock:
@@ -112,7 +186,8 @@ class _ServiceThread(threading.Thread):
     def __init__(self, conn: tcp.Connection, st: _ServerState, wid: int):
         super().__init__(daemon=True, name=f"ps-conn-{wid}")
         self.conn, self.st, self.wid = conn, st, wid
-        self.opt = st.shared_opt if st.shared_opt is not None else FlatOptimizer(st.flat, st.optimizer_spec)
+        self.index = wid             # replaced by the worker's own index when its START message arrives
+        self.opt = None
         self.grad = torch.empty_like(st.flat.grad, device="cpu")
 
     def run(self):
@@ -123,11 +198,17 @@ class _ServiceThread(threading.Thread):
                 kind, meta, payload = self.conn.recv(into=self.grad)
                 if kind == START:
                     print("start", flush=True)
+                    self.index = int(meta.get("index", self.wid))
+                    self.opt = st.optimizer_for(self.index)
                     st.barrier.wait(st.on_all_started)   # all workers said start
                     st.barrier.wait()                    # all ready to receive
-                    self.conn.send(WEIGHTS, {"version": st.version, "n": st.flat.total}, st.snapshot)
+                    self.conn.send(WEIGHTS, {"version": st.version, "n": st.flat.total,
+                                             "steps_done": int(st.resumed_from.get(self.index, 0))}, st.snapshot)
                 elif kind == TRAIN:
                     t0 = time.time()
+                    if self.opt is None:
+                        self.opt = st.optimizer_for(self.index)
+                    written = st.checkpoints_written
                     g = self.grad.to(st.flat.device) if st.flat.device.type != "cpu" else self.grad
                     if st.sync_mode == "sync":
                         with st.lock:
@@ -136,6 +217,7 @@ class _ServiceThread(threading.Thread):
                             else:
                                 self.opt.step(grad=g)
                                 st.version += 1
+                            st.count_step(self.index)
                         st.barrier.wait(st.on_round_complete)  # the completing thread takes ONE snapshot
                         reply = st.snapshot
                     else:
@@ -143,8 +225,13 @@ class _ServiceThread(threading.Thread):
                             st.staleness.append(st.version - int(meta.get("version", st.version)))
                             self.opt.step(grad=g)
                             st.version += 1
+                            st.count_step(self.index)
                             reply = st.flat.master.detach().cpu().clone()
-                    self.conn.send(WEIGHTS, {"version": st.version}, reply)
+                    # "checkpoint": the server has just written one that includes this step -- the worker adds its
+                    # own random-number state so that a resumed run draws the same dropout masks
+                    self.conn.send(WEIGHTS, {"version": st.version,
+                                             "checkpoint": bool(st.checkpoints_written != written
+                                                                and st.sync_mode == "sync")}, reply)
                     st.step_latency.append(time.time() - t0)
                 elif kind == END:
                     print("end", flush=True)
@@ -174,12 +261,18 @@ def start(sync_mode, model_fn, dataset_fn, n_nodes, optimizer=None, supervisor_a
           server_address="127.0.0.1", port: int = DEFAULT_PORT, apply: str = "reduced", device="cpu",
           cfg: TrainConfig | None = None, barrier_timeout: float = 600.0, accept_timeout: float = 600.0,
           result_queue=None, metrics_path: str | None = None, evaluate: bool = True, ready_event=None,
-          port_cell=None) -> dict:
+          port_cell=None, load_weights: str | None = None, save_weights: str | None = None,
+          checkpoint_dir: str | None = None, checkpoint_every: int = 0, resume: bool = False) -> dict:
     """Runs the parameter server until every worker has sent ``end``; then evaluates on the test
     split and prints the reference's two result lines. Signature follows reference
     centralized/server.py:139-140. ``port_cell`` (a shared ``multiprocessing.Value('i')``): the port the
     listener is bound to is published there -- with ``port=0`` the operating system picks it, so two jobs
-    on one host never collide."""
+    on one host never collide.
+
+    ``load_weights`` / ``save_weights``: Keras-ordered weight list the model starts from / is exported to after
+    training (the reference's wire format, server.py:96,150). ``checkpoint_dir`` + ``checkpoint_every=N``: a
+    checkpoint every N rounds (sync) or N applies per worker (async) and at the end; ``resume`` continues from it:
+    every worker is told how many of its steps the checkpoint contains and skips that many batches."""
     if sync_mode not in ("sync", "async"):
         raise ValueError("Invalid centralized strategy")
     if cpu_affinity:
@@ -188,7 +281,12 @@ def start(sync_mode, model_fn, dataset_fn, n_nodes, optimizer=None, supervisor_a
     torch.manual_seed(cfg.seed)
     replica = Replica(as_model(model_fn()), device, cfg)
     replica.reducer.detach()
+    if load_weights:
+        replica.model.load_weights(load_weights)
+        replica.flat.refresh_shadow()
     st = _ServerState(replica, n_nodes, sync_mode, apply, optimizer, barrier_timeout)
+    st.checkpoint_dir, st.checkpoint_every = checkpoint_dir, int(checkpoint_every or 0)
+    resumed = st.load_checkpoint() if resume else False
     sup = SupervisorSink(supervisor_address)
     sup.send("start")
     listener = tcp.Listener(server_address, port, backlog=50)
@@ -218,7 +316,13 @@ def start(sync_mode, model_fn, dataset_fn, n_nodes, optimizer=None, supervisor_a
     sup.send(["done", st.elapsed])
     if st.elapsed is None:
         st.elapsed = time.time() - st.start_time
+    if checkpoint_dir:
+        st.save_checkpoint()
+    if save_weights:
+        replica.flat.refresh_shadow()
+        replica.model.save_weights(save_weights)
     res = {"ok": True, "elapsed": st.elapsed, "versions": st.version, "departed_workers": len(st.errors),
+           "resumed": bool(resumed), "checkpoints_written": st.checkpoints_written,
            "mean_staleness": sum(st.staleness) / max(1, len(st.staleness)),
            "ps_step_latency_ms": 1e3 * sum(st.step_latency) / max(1, len(st.step_latency))}
     if evaluate:
@@ -242,9 +346,13 @@ def start(sync_mode, model_fn, dataset_fn, n_nodes, optimizer=None, supervisor_a
 def train(batch_size, model_fn=None, dataset_fn=None, num_epochs=1, index=0, n_nodes=0, cpu_affinity=False,
           server_address="127.0.0.1", port: int = DEFAULT_PORT, device="cpu", cfg: TrainConfig | None = None,
           connect_timeout: float = 120.0, io_timeout: float = 600.0, max_steps: int | None = None,
-          result_queue=None, fault_hook=None, metrics_path: str | None = None, port_cell=None) -> dict:
+          result_queue=None, fault_hook=None, metrics_path: str | None = None, port_cell=None,
+          checkpoint_dir: str | None = None, resume: bool = False, watchdog_s: float = 0.0) -> dict:
     """A parameter-server worker. Signature follows reference centralized/client.py:45-46. ``port_cell``:
-    wait for the server to publish its port there (see :func:`start`)."""
+    wait for the server to publish its port there (see :func:`start`). ``checkpoint_dir``: where this worker keeps
+    its random-number state next to the server's checkpoint; ``resume``: restore it and skip the batches of the
+    steps the server's checkpoint already contains. ``watchdog_s``: end the process (exit code 19) when a step
+    makes no progress for that long."""
     if cpu_affinity:
         pin_to_core(index + 1)  # core 0 is the parameter server's
     batch_size = int(batch_size)
@@ -272,11 +380,25 @@ def train(batch_size, model_fn=None, dataset_fn=None, num_epochs=1, index=0, n_n
     iteration = 0
     last = None
     dev = torch.device(device)
+    skip = int(meta.get("steps_done", 0)) if resume else 0
+    rng_path = os.path.join(checkpoint_dir, f"ps_worker{index}.pt") if checkpoint_dir else None
+    if skip and rng_path and os.path.exists(rng_path):
+        from ..utils.checkpoint import _set_rng_state
+        saved = torch.load(rng_path, map_location="cpu", weights_only=True)
+        if int(saved["steps"]) == skip:
+            _set_rng_state(saved["rng"], dev)
+    wd = None
+    if watchdog_s and watchdog_s > 0:
+        from ..comm.watchdog import Watchdog
+        wd = Watchdog(float(watchdog_s), rank=index)
     try:
         for _ in range(num_epochs):
             for x, y in dataset.iterate(dev):
                 if max_steps is not None and iteration >= max_steps:
                     break
+                if iteration < skip:           # a step the resumed checkpoint already contains
+                    iteration += 1
+                    continue
                 if fault_hook is not None:
                     fault_hook(index, iteration)
                 t0 = time.time()
@@ -293,11 +415,19 @@ def train(batch_size, model_fn=None, dataset_fn=None, num_epochs=1, index=0, n_n
                 if metrics.enabled:
                     metrics.log(step=iteration, loss=float(last), step_s=time.time() - t0, version=version)
                 iteration += 1
+                if wd is not None:
+                    wd.beat(f"step {iteration}")
+                if rng_path and meta.get("checkpoint"):
+                    from ..utils.checkpoint import _atomic_save, _rng_state
+                    os.makedirs(checkpoint_dir, exist_ok=True)
+                    _atomic_save({"steps": iteration, "rng": _rng_state(dev)}, rng_path)
+        if wd is not None:
+            wd.close()
         conn.send(END, {})
     finally:
         conn.close()
         metrics.close()
-    res = {"ok": True, "steps": iteration, "loss": float(last) if last is not None else None}
+    res = {"ok": True, "steps": iteration, "loss": float(last) if last is not None else None, "resumed_from": skip}
     if result_queue is not None:
         result_queue.put((f"worker{index}", dict(res)))
     return res

@@ -269,3 +269,52 @@ def test_watchdog_aborts_a_job_whose_peer_stalls(tmp_path):
     assert "[watchdog] rank 0" in p.stderr
     res = json.load(open(tmp_path / "r.json"))
     assert 19 in res["exit_codes"]
+
+
+def test_tcp_parameter_server_honours_checkpoint_resume_and_weight_flags(tmp_path):
+    """The framed-TCP topology (the one --device cpu selects): 10 rounds uninterrupted == 10 rounds with a worker
+    killed at step 7 and a resume from the server's step-5 checkpoint; --save-weights writes the server's model and
+    --load-weights starts the server from a file."""
+    import numpy as np
+    base = "-m c -cs sync --transport tcp --port 0 -n 2 -b 32 --max-steps 10 --checkpoint-every 5".split()
+    a = _run_launcher(base + ["--checkpoint-dir", str(tmp_path / "ckA"), "--save-weights", str(tmp_path / "A.npz")])
+    assert a.returncode == 0, a.stdout[-1500:] + a.stderr[-1500:]
+    assert (tmp_path / "ckA" / "ps_server.pt").exists() and (tmp_path / "A.npz").exists()
+    b1 = _run_launcher(base + ["--checkpoint-dir", str(tmp_path / "ckB"), "--fault-inject", "0:7", "--comm-timeout-s", "30"])
+    assert b1.returncode != 0
+    assert (tmp_path / "ckB" / "ps_server.pt").exists()
+    b2 = _run_launcher(base + ["--checkpoint-dir", str(tmp_path / "ckB"), "--resume", "--save-weights",
+                               str(tmp_path / "B.npz"), "--results", str(tmp_path / "resB.json")])
+    assert b2.returncode == 0, b2.stdout[-1500:] + b2.stderr[-1500:]
+    res = json.load(open(tmp_path / "resB.json"))
+    assert res["server"]["resumed"] is True
+    assert res["worker0"]["resumed_from"] == 5 and res["worker0"]["steps"] == 10
+    wa, wb = np.load(tmp_path / "A.npz"), np.load(tmp_path / "B.npz")
+    keys = [k for k in wa.files if k.startswith("weight_")]
+    assert keys
+    for k in keys:
+        assert np.array_equal(wa[k], wb[k]), k
+    # zero steps from the loaded file == the file
+    c = _run_launcher("-m c -cs sync --transport tcp --port 0 -n 1 -b 32 --max-steps 0".split()
+                      + ["--load-weights", str(tmp_path / "A.npz"), "--save-weights", str(tmp_path / "C.npz")])
+    assert c.returncode == 0, c.stderr[-1500:]
+    wc = np.load(tmp_path / "C.npz")
+    for k in keys:
+        assert np.array_equal(wa[k], wc[k]), k
+
+
+def test_load_weights_survives_the_first_asynchronous_apply(tmp_path):
+    """-cs async keeps the authoritative shard apart from the replica's arena: imported weights must reach it, or the
+    first apply continues from the seed-initialised weights. With a zero learning rate the exported model must equal
+    the imported one after training steps."""
+    import numpy as np
+    a = _run_launcher("-m d -ds keras -n 1 -b 32 --max-steps 3 --seed 5".split() + ["--save-weights", str(tmp_path / "w.npz")])
+    assert a.returncode == 0, a.stderr[-1500:]
+    env = dict(ENV)
+    cmd = [sys.executable, os.path.join(ROOT, "initializer.py"), *"-m c -cs async --transport collective -n 2 -b 32 --max-steps 2".split(),
+           "--device", "cpu", "--learning-rate", "0", "--load-weights", str(tmp_path / "w.npz"), "--save-weights", str(tmp_path / "w2.npz")]
+    b = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert b.returncode == 0, b.stdout[-1500:] + b.stderr[-1500:]
+    w, w2 = np.load(tmp_path / "w.npz"), np.load(tmp_path / "w2.npz")
+    for k in (k for k in w.files if k.startswith("weight_")):
+        assert np.array_equal(w[k], w2[k]), k

@@ -41,6 +41,10 @@ def main() -> int:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="", help="comma-separated back ends (default: all that apply)")
+    ap.add_argument("--ipc-blocks", type=int, default=0,
+                    help="CU budget (blocks) of the peer-pointer kernels; 0 = their defaults (64 for the single-launch one)")
+    ap.add_argument("--ipc-threads", type=int, default=256,
+                    help="widest block of the single-launch all-reduce (1024 where ranks share one GPU: blocks x ranks <= 256)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         import socket
@@ -78,7 +82,7 @@ def main() -> int:
     if dev.type == "cuda" and world > 1:
         try:
             from distributed_tensorflow_amd.comm.ipc import PeerGroup
-            peers = PeerGroup(comm)
+            peers = PeerGroup(comm, max_blocks=a.ipc_blocks, fused_threads=a.ipc_threads)
             backends += [f"ipc-{k}" for k in IPC]
         except Exception as e:      # no peer access between these devices / processes
             if rank == 0:
