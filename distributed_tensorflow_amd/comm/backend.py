@@ -158,12 +158,17 @@ class Comm:
                 out.copy_(inp)
             return None
         if self.composed:
-            # gloo has no reduce_scatter: reduce the whole buffer, keep the local slice
-            w = self.all_reduce(inp)
+            # gloo has no reduce_scatter: reduce the whole buffer, keep the local slice (asynchronous like the
+            # native collective: the strategies post it from a backward hook and must not block backward there)
             n = out.numel()
-            if out.data_ptr() != inp[self.rank * n:].data_ptr():
-                out.copy_(inp[self.rank * n:(self.rank + 1) * n])
-            return w
+            mine = inp[self.rank * n:(self.rank + 1) * n]
+            w = self.all_reduce(inp, async_op=async_op)
+            if out.data_ptr() == mine.data_ptr():
+                return w
+            if w is None:
+                out.copy_(mine)
+                return None
+            return _StagedWork([w], [(out, mine)])
         return dist.reduce_scatter_tensor(out, inp, group=self.group, async_op=async_op)
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):

@@ -103,6 +103,13 @@ class Strategy:
                 f"step {step}: master weights differ across ranks (checksum max {hi.tolist()} != min {lo.tolist()}; "
                 f"this rank {c.tolist()})")
 
+    def export_master(self) -> torch.Tensor:
+        """The whole fp32 master arena (a collective call where the strategy shards it)."""
+        return self.flat.master.detach().clone()
+
+    def import_master(self, full: torch.Tensor) -> None:
+        self.flat.write_master(full)
+
     def on_weights_loaded(self) -> None:
         """Called after ``flat.master`` has been rewritten from outside (weight import, checkpoint resume): a
         strategy that keeps parameter state apart from the replica's arena copies it from there."""

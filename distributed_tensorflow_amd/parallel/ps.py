@@ -39,17 +39,38 @@ from .base import Strategy
 
 
 class SyncPSStrategy(Strategy):
+    """Synchronous parameter server whose state is SHARDED across the ranks.
+
+    Rank r is the server of shard r of every gradient bucket. What it keeps of the server's state -- the fp32
+    master copy of the bf16 parameters and the optimizer moments -- is that shard only (1/W of the model; the
+    reference server owns the one model, reference centralized/server.py:148-150). Every rank keeps the working
+    parameters whole: the bf16 arena the layers read, and the fp32 parameters (norm scales / offsets, a model
+    trained in fp32), which are their own master copy.
+
+    Per bucket and step: reduce-scatter of the gradients while backward still runs (push) -> ONE fused optimizer
+    launch on the owned shard that also writes the shard's bf16 working copy -> all-gather of that bf16 arena slice
+    (pull; fp32 parameters travel as fp32). The all-gathers are posted back to back, first-needed bucket first, and
+    nobody waits for them at the end of the step: the NEXT forward pass waits for a bucket's pull when the first
+    layer holding one of its parameters is about to run (``pull_wait='first_use'``), so the bulk of the pull -- the
+    late layers' parameters -- travels under the early layers' forward. ``pull_wait='step_end'`` waits before the
+    step returns (the form a captured hipGraph needs, and the safe choice for a model that reads a parameter
+    outside the module that owns it, before that module has run).
+    """
     graph_capturable = True
     name = "sync"
     replicas_agree = True
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None, metrics=None,
-                 apply: str = "reduced", optimizer_state: str | None = None):
+                 apply: str = "reduced", optimizer_state: str | None = None, pull_wait: str | None = None,
+                 shard_master: bool = True):
         cfg = cfg or TrainConfig()
         cfg.shard_ways = max(cfg.shard_ways, comm.world)
+        cfg.split_dtypes = True              # bf16 parameters first: below the boundary the fp32 master is sharded
         super().__init__(model, comm, cfg, optimizer, metrics)
         if apply not in ("reduced", "sequential"):
             raise ValueError("apply must be 'reduced' or 'sequential'")
+        if pull_wait not in (None, "first_use", "step_end"):
+            raise ValueError("pull_wait must be 'first_use' or 'step_end'")
         self.apply = apply
         self.optimizer_state = optimizer_state or ("per_worker" if apply == "sequential" else "shared")
         W, r = comm.world, comm.rank
@@ -58,12 +79,70 @@ class SyncPSStrategy(Strategy):
         self.optimizers = [FlatOptimizer(self.flat, optimizer, state_ranges=self.shards) for _ in range(n_states)]
         self.optimizer = self.optimizers[0]
         self.broadcast_initial(0)
+        if shard_master and self.flat.split:
+            # from here on this rank holds 1/W of the fp32 master of the bf16 parameters
+            self.flat.shard_master([(a, e) for a, e in self.shards if a < self.flat.split])
         self._scale = 1.0 / W if (self.cfg.loss_reduction == "mean" and apply == "reduced") else 1.0
         if apply == "sequential" and W > 1:
             # room for every worker's copy of this rank's shard of every bucket
             self._gathered = torch.empty(self.flat.total, dtype=self.flat.grad.dtype, device=comm.device)
         self.bytes_pushed = 0
         self.bytes_pulled = 0
+        self.pull_wait = pull_wait or "first_use"
+        self._pulls: dict[int, object] = {}        # bucket index -> work handle of its all-gather in flight
+        self._hooks = []
+        if W > 1:
+            self._install_pull_hooks()
+
+    # ------------------------------------------------------------------ pull
+    def _install_pull_hooks(self) -> None:
+        """A forward pre-hook on every module that owns parameters: before it runs, the pulls of the buckets its
+        parameters live in must have landed."""
+        for mod in self.replica.model.modules():
+            idx = sorted({self.planner.slot_bucket[id(p)].index for p in mod._parameters.values()
+                          if p is not None and id(p) in self.planner.slot_bucket})
+            if idx:
+                self._hooks.append(mod.register_forward_pre_hook(self._make_hook(tuple(idx))))
+
+    def _make_hook(self, buckets: tuple):
+        pulls = self._pulls
+
+        def hook(_mod, _inp):
+            if pulls:
+                for i in buckets:
+                    w = pulls.pop(i, None)
+                    if w is not None:
+                        w.wait()
+        return hook
+
+    def wait_pulls(self) -> None:
+        """Every pull in flight has landed (before anything but the next forward pass reads the parameters)."""
+        for i in list(self._pulls):
+            w = self._pulls.pop(i)
+            if w is not None:
+                w.wait()
+
+    def _pull_view(self, a: int, e: int) -> torch.Tensor:
+        """What an owner broadcasts of [a, e): with a sharded master the bf16 working copy of bf16 parameters (2
+        bytes a parameter: nobody else holds their fp32 master), otherwise the fp32 master -- which for fp32
+        parameters is the parameter itself."""
+        f = self.flat
+        if f.master_base and a < f.master_base:
+            return f.shadow[a:e]
+        return f.m32(a, e)
+
+    def _post_pulls(self) -> None:
+        f = self.flat
+        # last bucket first: it holds the first layers, the ones the next forward pass needs first
+        for b, (a, e) in reversed(list(zip(self.planner.buckets, self.shards))):
+            whole, mine = self._pull_view(b.start, b.end), self._pull_view(a, e)
+            self._pulls[b.index] = self.comm.all_gather(whole, mine, async_op=True)
+            self.bytes_pulled += (b.numel - (e - a)) * whole.element_size()
+        if f.shadow is not None and not f.master_base:
+            self.wait_pulls()
+            f.refresh_shadow()       # whole fp32 master on every rank: the bf16 copies follow the gathered values
+        elif self.pull_wait == "step_end" or self.cfg.graph:
+            self.wait_pulls()
 
     # ------------------------------------------------------------------ push
     def _on_ready_reduced(self, b):
@@ -101,21 +180,55 @@ class SyncPSStrategy(Strategy):
                 for w in range(W):
                     opt = self.optimizers[w if len(self.optimizers) > 1 else 0]
                     opt.step(self.shards, grad=_Mapped(per_worker[w]))
-        # ------------------------------------------------------------- pull
         if W > 1:
             with phase("pull"):
-                # every bucket's all-gather is posted before any is waited for: the transfers queue back to back on
-                # the communication stream instead of alternating with host waits
-                works = []
-                for b, (a, e) in zip(self.planner.buckets, self.shards):
-                    works.append(self.comm.all_gather(f.master[b.start:b.end], f.master[a:e], async_op=True))
-                    self.bytes_pulled += (b.numel - (e - a)) * 4
-                for w in works:
-                    if w is not None:
-                        w.wait()
-                f.refresh_shadow()
+                self._post_pulls()
         self.apply_sparse()
         return loss
+
+    # ------------------------------------------------------- whole-model views
+    def evaluate(self, dataset, reduce: bool = True, max_batches: int | None = None):
+        self.wait_pulls()
+        return super().evaluate(dataset, reduce, max_batches)
+
+    def check_replicas(self, step: int = -1) -> None:
+        self.wait_pulls()
+        super().check_replicas(step)
+
+    def finalize(self) -> None:
+        self.wait_pulls()
+
+    def export_master(self) -> torch.Tensor:
+        """The whole fp32 master on every rank (collective): the owners' shards all-gathered into a temporary."""
+        self.wait_pulls()
+        f = self.flat
+        if not f.master_base:
+            return f.master.detach().clone()
+        full = torch.empty(f.total, dtype=torch.float32, device=f.device)
+        full[f.master_base:].copy_(f.master)
+        for b, (a, e) in zip(self.planner.buckets, self.shards):
+            if a < f.split:
+                full[a:e].copy_(f.m32(a, e))
+                w = self.comm.all_gather(full[b.start:b.end], full[a:e])
+                if w is not None:
+                    w.wait()
+        return full
+
+    def import_master(self, full: torch.Tensor) -> None:
+        self.wait_pulls()
+        self.flat.write_master(full)
+
+    def on_weights_loaded(self) -> None:
+        """A weight import wrote the working parameters (bf16 copies below the boundary): the owned fp32 shards
+        follow them, so that the next optimizer step starts from the imported model."""
+        f = self.flat
+        if f.master_base:
+            ranges, store = f.master_shards
+            base = 0
+            with torch.no_grad():
+                for a, e in ranges:
+                    store[base:base + e - a].copy_(f.shadow[a:e].float())
+                    base += e - a
 
 
 class _Mapped:

@@ -58,11 +58,12 @@ def save_checkpoint(directory: str, strategy, step: int | None = None, keras_exp
     os.makedirs(directory, exist_ok=True)
     comm, flat = strategy.comm, strategy.flat
     model = strategy.replica.model
+    master = strategy.export_master()           # collective where the master is sharded across the ranks
     if comm.rank == 0:
         slots = {s.name: {"offset": s.offset, "numel": s.numel, "shape": list(s.shape), "stride": list(s.stride)}
                  for s in flat.slots}
         buffers = {n: b.detach().cpu() for n, b in model.named_buffers() if b.is_floating_point() or b.dtype == torch.long}
-        _atomic_save({"master": flat.master.detach().cpu(), "slots": slots, "buffers": buffers,
+        _atomic_save({"master": master.detach().cpu(), "slots": slots, "buffers": buffers,
                       "step": int(step if step is not None else strategy.replica.step_count),
                       "strategy": strategy.name, "world": comm.world}, os.path.join(directory, "model.pt"))
         if keras_export:
@@ -81,12 +82,13 @@ def load_checkpoint(directory: str, strategy) -> int:
     model = strategy.replica.model
     ck = torch.load(os.path.join(directory, "model.pt"), map_location="cpu", weights_only=True)
     master = ck["master"]
-    for s in flat.slots:  # by name, so a checkpoint survives a different padding / shard count
+    full = torch.zeros(flat.total, dtype=torch.float32)
+    for s in flat.slots:  # by name, so a checkpoint survives a different padding / shard count / slot order
         src = ck["slots"][s.name]
         if src["numel"] != s.numel or list(src["shape"]) != list(s.shape):
             raise ValueError(f"checkpoint tensor {s.name} has shape {src['shape']}, model expects {list(s.shape)}")
-        flat.master[s.offset:s.offset + s.numel].copy_(master[src["offset"]:src["offset"] + s.numel])
-    flat.refresh_shadow()
+        full[s.offset:s.offset + s.numel].copy_(master[src["offset"]:src["offset"] + s.numel])
+    strategy.import_master(full)
     bufs = dict(model.named_buffers())
     for n, b in ck["buffers"].items():
         if n in bufs:

@@ -142,6 +142,7 @@ def _strategy_body(comm, kind, steps):
     x, y, _, _ = _make_data(comm.world, comm.rank)
     for _ in range(steps):
         st.train_step(x, y)
+    st.finalize()            # (the sharded parameter server's last pull may still be in flight)
     used = st.flat.used
     return st.flat.master[:used].clone().numpy(), [len(st.planner.buckets)]
 
@@ -221,6 +222,7 @@ def _sequential_body(comm, steps):
     x, y, _, _ = _make_data(comm.world, comm.rank)
     for _ in range(steps):
         st.train_step(x, y)
+    st.finalize()
     return st.flat.master[: st.flat.used].clone().numpy()
 
 
@@ -484,3 +486,70 @@ def test_async_ps_loses_no_update_under_concurrent_service_threads():
         assert "error" not in got[r], got[r].get("error")
         assert got[r]["applies"] == world * steps
         assert got[r]["equal"], got[r]
+
+
+# --------------------------------------------------------------------------- sharded synchronous parameter server
+def _mixed_model():
+    """bf16 weights with fp32 norm parameters and an fp32-kept bias: the mixed case the split arena layout is for."""
+    import torch.nn as nn
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Flatten(), nn.Linear(784, 64), nn.LayerNorm(64), nn.ReLU(), nn.Linear(64, 32), nn.ReLU(),
+                      nn.Linear(32, 10))
+    return m
+
+
+def _sharded_body(comm, kind, steps, pull_wait):
+    from distributed_tensorflow_amd.engine.optimizer import Adam
+    from distributed_tensorflow_amd.engine.replica import TrainConfig
+    from distributed_tensorflow_amd.parallel import mirrored, ps
+    cfg = TrainConfig(loss_reduction="mean", param_dtype=torch.bfloat16, bucket_bytes=40_000, first_bucket_bytes=6_000,
+                      last_bucket_bytes=None)
+    model = _mixed_model()
+    if kind == "keras":
+        st = mirrored.MirroredStrategy(model, comm, cfg, optimizer=Adam())
+    else:
+        st = ps.SyncPSStrategy(model, comm, cfg, optimizer=Adam(), pull_wait=pull_wait)
+    x, y, _, _ = _make_data(comm.world, comm.rank)
+    for _ in range(steps):
+        st.train_step(x, y)
+    st.finalize()
+    params = {n: p.detach().float().clone().numpy() for n, p in st.replica.model.named_parameters()}
+    info = {}
+    if kind != "keras":
+        f = st.flat
+        info = {"master_numel": f.master.numel() + f.master_shards[1].numel(), "total": f.total, "split": f.split,
+                "pulled": st.bytes_pulled, "buckets": len(st.planner.buckets),
+                "full_master": st.export_master().cpu().numpy(),
+                "slots": {s.name: (s.offset, s.numel) for s in f.slots}}
+    return params, info
+
+
+@pytest.mark.parametrize("world,pull_wait", [(2, "first_use"), (4, "first_use"), (2, "step_end")])
+def test_sharded_sync_ps_keeps_one_shard_of_the_master_and_pulls_bf16(world, pull_wait):
+    steps = 3
+    res = _run(_sharded_body, world, "sync", steps, pull_wait)
+    ref = _run(_sharded_body, world, "keras", steps, None)
+    p0, info = res[0]
+    # 1/W of the fp32 master of the bf16 parameters, all of the fp32 parameters
+    assert info["split"] > 0 and info["total"] > info["split"]
+    assert info["master_numel"] == info["split"] // world + (info["total"] - info["split"])
+    assert info["buckets"] > 2
+    # the pull moves 2 bytes per bf16 parameter and 4 per fp32 one, (W - 1) / W of each
+    want = steps * ((info["split"] * 2 + (info["total"] - info["split"]) * 4) * (world - 1) // world)
+    assert info["pulled"] == want
+    # every rank ends with the same working parameters, bit for bit
+    for p, _ in res[1:]:
+        for n in p0:
+            assert (p[n] == p0[n]).all(), n
+    # and they are the mirrored strategy's parameters up to the order of the gradient sums
+    k0 = ref[0][0]
+    for n in p0:
+        assert torch.allclose(torch.from_numpy(p0[n]), torch.from_numpy(k0[n]), rtol=2e-2, atol=2e-3), n
+    # the gathered fp32 master rounds to the bf16 working copy everywhere (no shard was left behind)
+    full = torch.from_numpy(info["full_master"])
+    for n, (off, numel) in info["slots"].items():
+        got = full[off:off + numel]
+        if off < info["split"]:
+            assert torch.equal(got.to(torch.bfloat16).float(), torch.from_numpy(p0[n]).reshape(-1)), n
+        else:
+            assert torch.equal(got, torch.from_numpy(p0[n]).reshape(-1)), n
