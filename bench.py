@@ -11,12 +11,18 @@ nothing is skipped inside the timed region.
 
 ``--strategy`` runs the same step under any other strategy (``custom:ring``, ``custom:direct``, ``ipc-direct``,
 ``graph:2``, ``sync``, ``async``); ``--model bert`` is BERT-base MLM at sequence length 512 (sequences/sec, by
-default under ``custom:ring``: the "custom bucketed all-reduce overlapped with backward" configuration).
+default under ``custom:direct``: the "custom bucketed all-reduce overlapped with backward" configuration on the
+schedule that fits a fully connected xGMI node -- one hop, all seven links of a GPU busy, three host-issued
+operations per bucket whatever the world size, where a single ring is bound by ONE link and costs 3 (W - 1)).
 
 Rank 0 prints one JSON line. Besides the throughput it carries evidence of what ran: ``ranks_seen`` (an
 all-reduce of ones over the process group), the communication backend, the bucket plan, a replica checksum
 comparison after the timed loop, and -- from a few extra, untimed steps bracketed with device events --
-per-phase device time with the exposed communication wait as a fraction of the step.
+per-phase device time with the exposed communication wait as a fraction of the step. With more than one rank the
+same phases are first measured on every rank ALONE (a world-1 strategy on the same model and batch, before the
+process group carries any traffic): ``backward_slowdown`` = backward at N ranks / backward alone is what the
+collectives cost the backward pass they overlap with (CU and HBM contention, a transfer that blocks where it is
+started), which the wait phases cannot show; ``comm_in_hook`` is the part of it spent starting collectives.
 """
 import argparse
 import json
@@ -45,13 +51,11 @@ def main() -> int:
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--bucket-mb", type=int, default=None, help="gradient bucket size (default 48 MiB)")
-    ap.add_argument("--conv1x1", default=None, choices=[None, "auto", "gemm", "library"])
-    ap.add_argument("--convkxk", default=None, choices=[None, "auto", "gemm", "library"])
     ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"], help="cpu is for plumbing tests only")
     ap.add_argument("--model", default="resnet50", choices=["resnet50", "bert", "bert-tiny"])
     ap.add_argument("--strategy", default=None,
                     help="keras | custom[:direct|ring|multiring|tree|oneshot] | ipc[-direct|-fused|-oneshot|-ring|-tree] | "
-                         "graph[:degree] | sync | async (default: keras for resnet50, custom:ring for bert)")
+                         "graph[:degree] | sync | async (default: keras for resnet50, custom:direct for bert)")
     ap.add_argument("--grad-dtype", default="bf16", choices=["bf16", "fp32"], help="dtype the gradients are exchanged in")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph")
     ap.add_argument("--input", default="device", choices=["device", "host"],
@@ -59,6 +63,8 @@ def main() -> int:
                          "uint8 images in host memory, gathered per step by the native loader threads, uploaded on a copy "
                          "stream one step ahead and normalised on the GPU (ResNet-50 only)")
     ap.add_argument("--phase-steps", type=int, default=3, help="untimed steps after the timed loop that measure per-phase device time (0 = skip)")
+    ap.add_argument("--ref-steps", type=int, default=3,
+                    help="with several ranks: steps of the single-rank reference measurement of the phases (0 = skip)")
     ap.add_argument("--comm-timeout-s", type=float, default=1200.0,
                     help="every collective of the process group fails after this many seconds instead of blocking")
     a = ap.parse_args()
@@ -93,33 +99,34 @@ def main() -> int:
     from distributed_tensorflow_amd import bench_lib
     from distributed_tensorflow_amd.comm.backend import Comm
     from distributed_tensorflow_amd.obs.trace import PhaseTimer
-    from distributed_tensorflow_amd.ops import _lib, conv
+    from distributed_tensorflow_amd.ops import _lib
 
     if dev.type == "cuda":
         _lib.kernels()
-    if a.conv1x1:
-        conv.set_conv1x1_backend(a.conv1x1)
-    if a.convkxk:
-        conv.set_convkxk_backend(a.convkxk)
     comm = Comm.from_env(dev, timeout_s=a.comm_timeout_s) if world > 1 else Comm(0, 1, dev)
     bucket_mb = a.bucket_mb or bench_lib.BUCKET_MB
     gdt = torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32
     if a.model == "resnet50":
         strategy = a.strategy or "keras"
         batch = a.batch or int(os.environ.get("DTF_BENCH_BATCH", "1024"))
-        st = bench_lib.make_resnet50_strategy(comm, bucket_mb=bucket_mb, grad_dtype=gdt, strategy=strategy)
+
+        def make(c, s_):
+            return bench_lib.make_resnet50_strategy(c, bucket_mb=bucket_mb, grad_dtype=gdt, strategy=s_)
         x, y = bench_lib.synthetic_imagenet_batch(batch, dev, size=a.image, seed=rank)
         metric, unit = "images/sec (whole node) ResNet-50 sync DP", "images/sec"
         cfg_model = {"model": "resnet50", "image": a.image, "seq_len": None,
                      "optimizer": "sgd-momentum (fused flat-arena kernel)"}
     else:
         from distributed_tensorflow_amd.models.bert import synthetic_mlm_batch
-        strategy = a.strategy or "custom:ring"
+        strategy = a.strategy or "custom:direct"
         batch = a.batch or 128
         size = "base" if a.model == "bert" else "tiny"
         seq = a.seq_len if size == "base" else min(a.seq_len, 64)
-        st = bench_lib.make_bert_strategy(comm, size, seq, bucket_mb=bucket_mb, grad_dtype=gdt, strategy=strategy)
-        x, y = synthetic_mlm_batch(batch, seq, st.replica.model.vocab, dev, n_pred=min(80, seq // 4), seed=rank)
+
+        def make(c, s_):
+            return bench_lib.make_bert_strategy(c, size, seq, bucket_mb=bucket_mb, grad_dtype=gdt, strategy=s_)
+        vocab = 30522 if size == "base" else 1024
+        x, y = synthetic_mlm_batch(batch, seq, vocab, dev, n_pred=min(80, seq // 4), seed=rank)
         metric, unit = "sequences/sec (whole node) BERT-base MLM seq 512", "sequences/sec"
         cfg_model = {"model": "bert-base-mlm" if size == "base" else "bert-tiny-mlm", "image": None, "seq_len": seq,
                      "optimizer": "adam (fused flat-arena kernel)"}
@@ -128,6 +135,22 @@ def main() -> int:
         comm.barrier()
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
+
+    # ---- single-rank reference of the phases: every rank alone, before the process group carries traffic
+    ref_phase = {}
+    if world > 1 and a.ref_steps > 0 and not a.graph:
+        ref = make(Comm(0, 1, dev), "keras")
+        for _ in range(2):
+            ref.train_step(x, y)
+        with PhaseTimer(dev) as pt:
+            for _ in range(a.ref_steps):
+                ref.train_step(x, y)
+            ref_phase = {k: round(v, 3) for k, v in pt.report().items()}
+        del ref
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
+    st = make(comm, strategy)
 
     # proof of the process group: every rank contributes a one
     ones = torch.ones(1, dtype=torch.float32, device=dev)
@@ -178,8 +201,20 @@ def main() -> int:
             sync()
             step_ms = (time.perf_counter() - tp) * 1e3 / a.phase_steps
             phase_ms = {k: round(v, 3) for k, v in pt.report().items()}
-        wait = sum(v for k, v in phase_ms.items() if k in ("grad_sync_wait", "push_wait", "pull", "push_pull", "gossip"))
+        wait = sum(v for k, v in phase_ms.items()
+                   if k in ("grad_sync_wait", "push_wait", "pull", "push_pull", "gossip", "comm_in_hook"))
         exposed = round(wait / step_ms, 4) if step_ms > 0 else None
+    # host side of the communication: time inside the bucket-ready callbacks and operations issued per bucket
+    red = st.replica.reducer
+    hook_ms = round(red.hook_host_s * 1e3 / max(1, st.replica.step_count), 3)
+    from distributed_tensorflow_amd.comm import algorithms as _alg
+    ops_per_bucket = None
+    if red.hook_calls and strategy.startswith("custom"):
+        ops_per_bucket = round((_alg.stats["exchanges"] + _alg.stats["kernels"]) / red.hook_calls, 2)
+    slowdown = None
+    if ref_phase.get("backward") and phase_ms.get("backward"):
+        # the hook's share is communication (reported on its own), not a slower backward pass
+        slowdown = round((phase_ms["backward"] - phase_ms.get("comm_in_hook", 0.0)) / ref_phase["backward"], 4)
     if feed is not None:
         feed.close()
     st.finalize()
@@ -205,13 +240,16 @@ def main() -> int:
             "input": "one GPU-resident batch" if feed is None else "host uint8 pool -> loader threads -> pinned -> copy stream",
             "config": {**cfg_model, "global_batch": batch * world, "per_gpu_batch": batch,
                        "parallelism": f"dp{world}", "strategy": strategy, "grad_dtype": a.grad_dtype,
-                       "conv1x1": conv.get_conv1x1_backend(), "convkxk": conv.get_convkxk_backend(),
+                       "kernels": "own (gemm.hip / gemm256.hip / norm.hip ...): no vendor-library compute route",
                        "hip_graph": st.cfg.graph},
             "ranks_seen": ranks_seen, "comm_backend": comm.backend if world > 1 else "none (single rank)",
             "ms_per_step_fastest_rank": round(dt_min / a.steps * 1e3, 3),
             "buckets": {"count": len(buckets), "cap_mib": bucket_mb, "total_mib": round(sum(buckets) / 2 ** 20, 2),
                         "largest_mib": round(max(buckets) / 2 ** 20, 2)},
-            "phase_ms": phase_ms, "exposed_comm_fraction": exposed, "replicas_agree": agree,
+            "phase_ms": phase_ms, "exposed_comm_fraction": exposed,
+            "phase_ms_single_rank_reference": ref_phase, "backward_slowdown": slowdown,
+            "comm_host_ms_per_step": hook_ms, "comm_host_ops_per_bucket": ops_per_bucket,
+            "replicas_agree": agree,
             "final_loss": loss_v,
         }), flush=True)
     comm.shutdown()

@@ -270,12 +270,15 @@ class MaxPooling2D(_Pool2D):
         k, s = self.pool_size, self.strides
         if k[0] == k[1] and s[0] == s[1]:
             return _pool.max_pool2d(x, k[0], s[0])
+        if x.is_cuda:
+            from ..ops import generic_nn as _gen
+            return _gen.max_pool2d(x, k, s)
         return F.max_pool2d(x, k, s)
 
 
 class AveragePooling2D(_Pool2D):
     def forward(self, x):
-        return F.avg_pool2d(x, self.pool_size, self.strides)
+        return _pool.avg_pool2d(x, self.pool_size, self.strides)
 
 
 class GlobalAveragePooling2D(Layer):
@@ -309,6 +312,13 @@ class BatchNormalization(Layer):
                 x = x.contiguous(memory_format=torch.channels_last)
             return _norm.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
                                         bn.momentum, bn.eps, relu=False)
+        if x.is_cuda and x.dim() in (2, 4) and x.dtype in (torch.float32, torch.bfloat16):
+            # every other GPU case (fp32, any width, [N, C] inputs): the framework's general kernels
+            from ..ops import generic_nn as _gen
+            if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            return _gen.batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum,
+                                   bn.eps)
         return bn(x)
 
     def keras_weights(self):
@@ -331,6 +341,9 @@ class Embedding(Layer):
         return tuple(in_shape) + (self.emb.embedding_dim,)
 
     def forward(self, x):
+        if self.emb.weight.is_cuda:
+            from ..ops import embedding as _emb
+            return _emb.embedding(self.emb.weight, x)      # own gather / sorted-run gradient kernels
         return self.emb(x)
 
     def keras_weights(self):

@@ -53,7 +53,7 @@ def make_resnet50_strategy(comm: Comm, classes: int = 1000, bucket_mb: int = BUC
 
 
 def make_bert_strategy(comm: Comm, size: str = "base", seq_len: int = 512, bucket_mb: int = BUCKET_MB,
-                       grad_dtype=torch.bfloat16, seed: int = 0, strategy: str = "custom:ring"):
+                       grad_dtype=torch.bfloat16, seed: int = 0, strategy: str = "custom:direct"):
     from .models import bert
     torch.manual_seed(seed)
     model = bert.bert_base(seq_len) if size == "base" else bert.bert_tiny(seq_len)

@@ -14,10 +14,12 @@ centralized/client.py:83-90).
 from __future__ import annotations
 
 import ctypes
+import time
 from typing import Any, Callable
 
 import torch
 
+from ..obs.trace import phase
 from ..ops import _lib
 from ..ops import bucket as bops
 from .flat import Bucket, BucketPlanner, FlatParams
@@ -42,6 +44,8 @@ class GradReducer:
         self.enabled = True
         self._in_step = False
         self._plans: dict = {}
+        self.hook_host_s = 0.0             # host time spent inside on_ready callbacks (reset by the caller)
+        self.hook_calls = 0
 
     # ----------------------------------------------------------------- hooks
     def attach(self) -> None:
@@ -81,7 +85,13 @@ class GradReducer:
             b = self.planner.buckets[self._next]
             self._pack(b)
             if self.on_ready is not None:
-                self.works[b.index] = self.on_ready(b)
+                # its own phase inside ``backward``: what a collective costs where it is STARTED (a staged or
+                # synchronous transfer blocks here) is communication, not backward compute
+                t0 = time.perf_counter()
+                with phase("comm_in_hook"):
+                    self.works[b.index] = self.on_ready(b)
+                self.hook_host_s += time.perf_counter() - t0
+                self.hook_calls += 1
             self._next += 1
 
     # ------------------------------------------------------------------ pack

@@ -63,6 +63,9 @@ class PhaseTimer:
         _active_timer = None
 
     def report(self) -> dict[str, float]:
+        """Milliseconds PER STEP of every phase. A step is counted by its ``forward`` phase; a phase that occurs
+        several times in a step (``comm_in_hook``: once per gradient bucket) is the sum of its occurrences. Without
+        a ``forward`` phase (a loop that is not a training step) every phase is averaged over its own occurrences."""
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         for name, s, e in self.pending:
@@ -70,7 +73,8 @@ class PhaseTimer:
             self.totals[name] = self.totals.get(name, 0.0) + ms
             self.counts[name] = self.counts.get(name, 0) + 1
         self.pending.clear()
-        return {k: v / self.counts[k] for k, v in self.totals.items()}
+        steps = self.counts.get("forward", 0)
+        return {k: v / (steps if steps else self.counts[k]) for k, v in self.totals.items()}
 
 
 @contextlib.contextmanager

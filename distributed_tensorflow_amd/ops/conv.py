@@ -13,10 +13,10 @@ data gradient and split-K weight gradient are implicit GEMMs on the NHWC bytes.
   width -- two neighbouring pixels then form one 8-"channel" pixel of a half-width image, and a ``KW``-tap row
   becomes ``ceil((KW + P % 2) / 2)`` taps of stride 1 -- and to 8 channels otherwise.
 
-``set_conv1x1_backend`` / ``set_convkxk_backend`` (``'auto' | 'gemm' | 'library'``, defaults from the
-``DTF_CONV1X1`` / ``DTF_CONVKXK`` environment variables) exist for A/B timing against the vendor convolution
-library (``tools/bench_conv.py``); ``'auto'`` and ``'gemm'`` both mean the framework's own kernel for every pass.
-fp32 and CPU tensors take the torch composition.
+There is no route to a vendor convolution library: bf16 geometries the implicit-GEMM kernel does not take and fp32
+tensors run as patch matrix times weight matrix on the general-purpose exact-fp32 MFMA GEMM (:class:`_ConvAnyFn`);
+only CPU tensors (the plumbing mode) use ``torch.nn.functional.conv2d``. ``tools/bench_conv.py`` times the vendor
+library next to these kernels by calling it directly.
 """
 from __future__ import annotations
 
@@ -30,35 +30,6 @@ import torch.nn.functional as F
 from . import _lib
 from . import gemm as _gemm
 from . import gemm_any as _any
-
-_backend = os.environ.get("DTF_CONV1X1", "auto")
-_backend_kxk = os.environ.get("DTF_CONVKXK", "auto")
-_NAMES = ("auto", "gemm", "library")
-
-
-def set_conv1x1_backend(name: str) -> None:
-    global _backend
-    if name not in _NAMES:
-        raise ValueError("backend must be 'auto', 'gemm' or 'library'")
-    _backend = name
-
-
-def get_conv1x1_backend() -> str:
-    return _backend
-
-
-def set_convkxk_backend(name: str) -> None:
-    """Route of convolutions with a kernel larger than 1x1: 'gemm' (implicit GEMM on the MFMA kernel)
-    or 'library' (vendor convolution library)."""
-    global _backend_kxk
-    if name not in _NAMES:
-        raise ValueError("backend must be 'auto', 'gemm' or 'library'")
-    _backend_kxk = name
-
-
-def get_convkxk_backend() -> str:
-    return _backend_kxk
-
 
 class _SideGrads:
     """Weight gradients on a second stream.
@@ -464,14 +435,14 @@ def _norm_request(x):
     return _norm.request_of(x) if (_bn_grad_stats and torch.is_grad_enabled()) else None
 
 
-def _own_path(x, w, stride, backend) -> bool:
-    return (backend != "library" and stride in (1, 2) and _gemm_ok(x, w)
+def _own_path(x, w, stride) -> bool:
+    return (stride in (1, 2) and _gemm_ok(x, w)
             and (stride == 1 or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)))
 
 
-def _first_layer_path(x, w, stride, backend) -> bool:
+def _first_layer_path(x, w, stride) -> bool:
     """Few-channel image input (see :class:`_FirstConvFn`)."""
-    return (backend != "library" and stride in (1, 2) and x.is_cuda and x.dtype == torch.bfloat16
+    return (stride in (1, 2) and x.is_cuda and x.dtype == torch.bfloat16
             and w.dtype == torch.bfloat16 and x.shape[1] % 8 != 0 and x.shape[1] <= 64 and w.shape[0] % 8 == 0
             and x.is_contiguous(memory_format=torch.channels_last)
             and (stride == 1 or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)))
@@ -491,22 +462,20 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0, 
     ``y`` over disjoint row sets, accumulated while the GEMM stores ``y`` (pass them to
     ``ops.norm.batch_norm_act(..., partials=)``, which then reads ``y`` once instead of twice), or ``None`` when
     the convolution did not run on the framework's own kernel."""
-    one = w.shape[2] == 1 and w.shape[3] == 1
-    backend = _backend if one else _backend_kxk
     from . import norm as _norm
     if isinstance(x, _norm.DeferredNorm):
         dn, x = x, x.tensor
-        if _own_path(x, w, stride, backend):
+        if _own_path(x, w, stride):
             st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
-            y = _ConvFn.apply(x, w, stride, padding, backend == "auto", st, _norm_request(x), None, None, None,
+            y = _ConvFn.apply(x, w, stride, padding, True, st, _norm_request(x), None, None, None,
                               dn.scale, dn.shift, dn.relu)
             return (y, st) if bn_stats else y
         x = dn.materialize()
-    if _own_path(x, w, stride, backend):
+    if _own_path(x, w, stride):
         st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
-        y = _ConvFn.apply(x, w, stride, padding, backend == "auto", st, _norm_request(x))
+        y = _ConvFn.apply(x, w, stride, padding, True, st, _norm_request(x))
         return (y, st) if bn_stats else y
-    if _first_layer_path(x, w, stride, backend):
+    if _first_layer_path(x, w, stride):
         st = None
         if bn_stats and _bn_stats:
             st = torch.empty((_FirstConvFn.stats_rows(x, w, stride, padding), 2, w.shape[0]), dtype=torch.float32,
@@ -515,7 +484,15 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int = 0, 
         return (y, st) if bn_stats else y
     if x.dtype != w.dtype:
         x = x.to(w.dtype)
-    y = F.conv2d(x, w, None, stride, padding)
+    if x.is_cuda and _any.usable(x, w):
+        # fp32 layers and whatever geometry is left: patch matrix x weight matrix on the general MFMA GEMM
+        K, _, KH, KW = w.shape
+        OH = (x.shape[2] + 2 * padding - KH) // stride + 1
+        OW = (x.shape[3] + 2 * padding - KW) // stride + 1
+        wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
+        y = _ConvAnyFn.apply(x, wc, None, stride, stride, padding, padding, OH, OW, None)
+        return (y, None) if bn_stats else y
+    y = F.conv2d(x, w, None, stride, padding)        # CPU (plumbing mode)
     return (y, None) if bn_stats else y
 
 
@@ -523,13 +500,11 @@ def conv2d_fork(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int 
     """``(conv2d(x, w), x')`` where ``x'`` aliases ``x``: use ``x'`` for the other consumer of ``x`` (a
     residual branch) so that the two gradients of ``x`` are summed inside the data-gradient GEMM.
     With ``bn_stats=True`` the result is ``(y, x', partials)`` (see :func:`conv2d`)."""
-    one = w.shape[2] == 1 and w.shape[3] == 1
-    backend = _backend if one else _backend_kxk
-    if _own_path(x, w, stride, backend) and x.requires_grad and torch.is_grad_enabled():
+    if _own_path(x, w, stride) and x.requires_grad and torch.is_grad_enabled():
         st = _stats_buffer(x, w, stride, padding) if (bn_stats and _bn_stats) else None
         from . import norm as _norm
         token = _norm.ForkToken() if (_bn_grad_stats and w.shape[2] == 1 and w.shape[3] == 1 and stride == 1) else None
-        y, xi = _ConvForkFn.apply(x, w, stride, padding, backend == "auto", st, _norm_request(x), token)
+        y, xi = _ConvForkFn.apply(x, w, stride, padding, True, st, _norm_request(x), token)
         if token is not None:
             setattr(xi, _norm._TOKEN_ATTR, token)
         return (y, xi, st) if bn_stats else (y, xi)
@@ -603,11 +578,11 @@ def conv2d_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None,
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
-        square = sh == sw and pt == pl and _backend_kxk != "library"
+        square = sh == sw and pt == pl
         if square and x.dtype == torch.bfloat16 and N * max(H * W, OH * OW) < (1 << 24):
-            if _own_path(x, wc, sh, "gemm"):
+            if _own_path(x, wc, sh):
                 return _ConvFn.apply(x, wc, sh, pt, False, None, None, bias, act, (OH, OW))
-            if _first_layer_path(x, wc, sh, "gemm"):
+            if _first_layer_path(x, wc, sh):
                 return _FirstConvFn.apply(x, wc, sh, pt, None, bias, act, (OH, OW))
         if x.dtype in (torch.float32, torch.bfloat16):
             return _ConvAnyFn.apply(x, wc, bias, sh, sw, pt, pl, OH, OW, act)

@@ -335,8 +335,13 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, mo
                                              _lib.stream_ptr(x.device))
         _lib.check(rc, "bn_fwd_apply")
         return y
+    from . import generic_nn as _gen
+    if _gen.usable(x):
+        # fp32 activations (the launcher's default dtype) and channel counts the 16-byte kernels do not take: the
+        # framework's general kernels, not the vendor library's
+        return _gen.batch_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, residual)
     y = F.batch_norm(x.float() if x.dtype != torch.float32 and not x.is_cuda else x, running_mean, running_var,
-                     gamma, beta, training, momentum, eps)
+                     gamma, beta, training, momentum, eps)      # CPU (plumbing mode)
     y = y.to(x.dtype)
     if residual is not None:
         y = y + residual

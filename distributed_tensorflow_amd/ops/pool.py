@@ -1,8 +1,9 @@
 """Max pooling and global average pooling of channels_last (NHWC) activations.
 
-bf16 GPU tensors with a channel count that is a multiple of 8 run on the hand-written kernels of
+bf16 GPU tensors with a channel count that is a multiple of 8 run on the 16-byte kernels of
 ``csrc/kernels/pool.hip`` (forward records the winning tap in one byte per element; backward is
-an atomics-free gather); everything else uses ``torch.nn.functional.max_pool2d``.
+an atomics-free gather); any other GPU tensor (fp32, odd channel counts, rectangular windows) on the general kernels
+of ``csrc/kernels/generic_nn.hip``; only CPU tensors use ``torch.nn.functional``.
 """
 from __future__ import annotations
 
@@ -10,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
+from . import generic_nn as _gen
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -44,7 +46,15 @@ def max_pool2d(x: torch.Tensor, kernel_size: int, stride: int | None = None, pad
     if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0 and padding < kernel_size
             and x.is_contiguous(memory_format=torch.channels_last)):
         return _MaxPoolFn.apply(x, kernel_size, s, padding)
+    if _gen.usable(x) and x.dim() == 4:
+        return _gen.max_pool2d(x, kernel_size, s, padding)
     return F.max_pool2d(x, kernel_size, s, padding)
+
+
+def avg_pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0) -> torch.Tensor:
+    if _gen.usable(x) and x.dim() == 4:
+        return _gen.avg_pool2d(x, kernel_size, stride, padding)
+    return F.avg_pool2d(x, kernel_size, stride, padding)
 
 
 class _GlobalAvgPoolFn(torch.autograd.Function):
@@ -74,4 +84,6 @@ def global_avg_pool(x: torch.Tensor) -> torch.Tensor:
     if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
             and x.is_contiguous(memory_format=torch.channels_last)):
         return _GlobalAvgPoolFn.apply(x)
+    if _gen.usable(x) and x.dim() == 4 and x.shape[0] <= 65535:
+        return _gen.global_avg_pool(x)
     return x.mean(dim=(2, 3))

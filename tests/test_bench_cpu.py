@@ -115,6 +115,14 @@ def test_bench_every_strategy_two_ranks_and_eight(strategy, world):
     assert "forward" in r["phase_ms"] and "backward" in r["phase_ms"]
     if strategy in ("keras", "sync"):
         assert r["exposed_comm_fraction"] is not None
+    # contention evidence: the same phases on one rank alone, and where the collectives are started
+    assert "backward" in r["phase_ms_single_rank_reference"] and r["backward_slowdown"] > 0
+    if strategy != "async" and not strategy.startswith("graph"):
+        assert "comm_in_hook" in r["phase_ms"] and r["comm_host_ms_per_step"] > 0
+    if strategy == "custom:direct":
+        assert r["comm_host_ops_per_bucket"] == 3.0         # two grouped exchanges + one reduction, at any world size
+    if strategy == "custom:ring":
+        assert r["comm_host_ops_per_bucket"] == 3.0 * (world - 1)
 
 
 def test_collective_harness_two_ranks_gloo():

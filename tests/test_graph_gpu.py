@@ -73,9 +73,6 @@ def test_training_is_bit_identical_across_runs_with_a_fixed_seed(model_name):
     from distributed_tensorflow_amd.parallel.mirrored import MirroredStrategy
 
     dev = torch.device("cuda:0")
-    saved = conv.get_conv1x1_backend(), conv.get_convkxk_backend()
-    conv.set_conv1x1_backend("gemm")          # the vendor library's weight-gradient kernels use atomics
-    conv.set_convkxk_backend("gemm")
     try:
         def run():
             torch.manual_seed(0)
@@ -101,8 +98,7 @@ def test_training_is_bit_identical_across_runs_with_a_fixed_seed(model_name):
         l1, w1 = run()
         l2, w2 = run()
     finally:
-        conv.set_conv1x1_backend(saved[0])
-        conv.set_convkxk_backend(saved[1])
+        pass
     assert l1 == l2
     assert w1.keys() == w2.keys()
     for k in w1:

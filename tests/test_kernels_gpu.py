@@ -278,8 +278,7 @@ def test_implicit_gemm_conv_matches_fp32_autograd(cfg):
     dy = torch.randn(yr.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).to(torch.bfloat16)
     yr.backward(dy.float())
     ref = (yr.detach(), xr.grad, wr.grad)
-    for be in ("gemm", "auto"):
-        conv.set_conv1x1_backend(be); conv.set_convkxk_backend(be)
+    for be in ("own",):
         x1 = x.clone().requires_grad_(True); w1 = w.clone().requires_grad_(True)
         y = conv.conv2d(x1, w1, stride, pad)
         assert y.shape == yr.shape and y.dtype == torch.bfloat16
@@ -288,7 +287,6 @@ def test_implicit_gemm_conv_matches_fp32_autograd(cfg):
             scale = max(1.0, float(b.abs().max()))
             torch.testing.assert_close(a / scale, b / scale, rtol=2e-2, atol=1e-2,
                                        msg=lambda m: be + " " + name + ": " + m)
-    conv.set_conv1x1_backend("auto"); conv.set_convkxk_backend("auto")
 
 
 def test_first_layer_conv_hands_over_batch_norm_statistics():
@@ -964,9 +962,6 @@ def test_norm_backward_sums_from_the_consuming_convolution(block):
             m.bias.data.normal_(0, 0.3)
     net.train()
     x = x.bfloat16().contiguous(memory_format=torch.channels_last)
-    saved = conv.get_conv1x1_backend(), conv.get_convkxk_backend()
-    conv.set_conv1x1_backend("gemm")
-    conv.set_convkxk_backend("gemm")
     grads = {}
     with torch.no_grad():
         n_out = net(x).numel()
@@ -985,8 +980,6 @@ def test_norm_backward_sums_from_the_consuming_convolution(block):
             grads[tag]["input"] = xi.grad.float().clone()
     finally:
         conv.set_bn_stats(True)
-        conv.set_conv1x1_backend(saved[0])
-        conv.set_convkxk_backend(saved[1])
 
     # fp32 reference: the same blocks from torch's fp32 convolution / batch norm on the bf16-rounded weights
     def bn(m, t, res=None):
@@ -1431,3 +1424,149 @@ def test_deferred_norm_is_applied_by_the_consuming_convolution(cfg):
         for other in (m_, c):
             scale = max(1.0, float(other.abs().max()))
             torch.testing.assert_close(a / scale, other / scale, rtol=1e-2, atol=1e-2, msg=lambda m: name + ": " + m)
+
+
+# ------------------------------------------------------------------ general (any dtype / width) norm and pooling kernels
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(6, 3, 9, 7), (4, 10, 5, 5), (3, 64, 8, 8), (2, 100, 6, 4), (33, 20), (5000, 7, 3, 3)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
+def test_general_batch_norm_matches_fp32_autograd(dtype, shape, relu, res):
+    """Training-mode batch norm (+ residual, + ReLU) of fp32 / bf16 activations of any width on generic_nn.hip: output,
+    all gradients and the running statistics against torch's fp32 batch norm on the same rounded inputs."""
+    from distributed_tensorflow_amd.ops import generic_nn as G
+    torch.manual_seed(sum(shape))
+    C = shape[1]
+    x = (torch.randn(shape, device=DEV) * 2 + 0.5).to(dtype)
+    if len(shape) == 4:
+        x = x.contiguous(memory_format=torch.channels_last)
+    r = torch.randn(shape, device=DEV).to(dtype) if res else None
+    gamma = (torch.rand(C, device=DEV) + 0.5); beta = torch.randn(C, device=DEV) * 0.3
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    rm2, rv2 = rm.clone(), rv.clone()
+    x1 = x.clone().requires_grad_(True); g1 = gamma.clone().requires_grad_(True); b1 = beta.clone().requires_grad_(True)
+    r1 = r.clone().requires_grad_(True) if res else None
+    y = G.batch_norm(x1, g1, b1, rm, rv, True, 0.1, 1e-5, relu, r1)
+    dy = torch.randn(shape, device=DEV).to(dtype)
+    y.backward(dy)
+    xr = x.detach().clone().float().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    rr = r.detach().clone().float().requires_grad_(True) if res else None
+    yr = torch.nn.functional.batch_norm(xr, rm2, rv2, gr, br, True, 0.1, 1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.float())
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(y.float(), yr.detach(), **tol)
+    torch.testing.assert_close(x1.grad.float(), xr.grad, **tol)
+    n = x.numel() // C
+    ptol = dict(rtol=2e-3, atol=2e-3 * max(1.0, n ** 0.5 / 8)) if dtype == torch.float32 else dict(rtol=5e-2, atol=0.05 * n ** 0.5)
+    torch.testing.assert_close(g1.grad, gr.grad, **ptol)
+    torch.testing.assert_close(b1.grad, br.grad, **ptol)
+    if res:
+        torch.testing.assert_close(r1.grad.float(), rr.grad, **tol)
+    torch.testing.assert_close(rm, rm2, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rv, rv2, rtol=1e-3, atol=1e-3)
+    # inference mode: the running statistics
+    with torch.no_grad():
+        ye = G.batch_norm(x, gamma, beta, rm, rv, False, 0.1, 1e-5, relu, r)
+        yre = torch.nn.functional.batch_norm(x.float(), rm2, rv2, gamma, beta, False, 0.1, 1e-5)
+        if res:
+            yre = yre + r.float()
+        if relu:
+            yre = torch.relu(yre)
+    torch.testing.assert_close(ye.float(), yre, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [((4, 3, 12, 10), 2, 2, 0), ((2, 16, 9, 9), 3, 2, 1), ((3, 10, 8, 11), (2, 3), (2, 1), (0, 1)),
+                                 ((2, 64, 7, 7), 3, 1, 1), ((1, 5, 6, 6), (3, 2), (1, 2), 0)])
+def test_general_pooling_matches_torch(dtype, cfg):
+    from distributed_tensorflow_amd.ops import generic_nn as G
+    shape, k, s, p = cfg
+    torch.manual_seed(shape[1])
+    x = torch.randn(shape, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    for mine, ref in ((G.max_pool2d, torch.nn.functional.max_pool2d), (G.avg_pool2d, torch.nn.functional.avg_pool2d)):
+        x1 = x.clone().requires_grad_(True)
+        y = mine(x1, k, s, p)
+        # reference on the CPU in fp32 (the vendor library's average-pool gradient for padded, overlapping windows of
+        # channels_last tensors disagrees with torch's own CPU kernel on this platform)
+        xr = x.detach().cpu().float().contiguous().requires_grad_(True)
+        yr = ref(xr, k, s, p)
+        assert y.shape == yr.shape
+        dy = torch.randn(yr.shape).to(dtype)
+        y.backward(dy.to(DEV))
+        yr.backward(dy.float())
+        tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(y.float().cpu(), yr.detach(), **tol)
+        torch.testing.assert_close(x1.grad.float().cpu(), xr.grad, **tol)
+    x1 = x.clone().requires_grad_(True)
+    g = G.global_avg_pool(x1)
+    xr = x.detach().clone().float().requires_grad_(True)
+    gr = xr.mean(dim=(2, 3))
+    dg = torch.randn(gr.shape, device=DEV).to(dtype)
+    g.backward(dg); gr.backward(dg.float())
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(g.float(), gr.detach(), **tol)
+    torch.testing.assert_close(x1.grad.float(), xr.grad, **tol)
+
+
+def test_general_max_pool_propagates_nan_and_picks_the_first_maximum():
+    from distributed_tensorflow_amd.ops import generic_nn as G
+    x = torch.zeros(1, 1, 4, 4, device=DEV).contiguous(memory_format=torch.channels_last)
+    x[0, 0, 0, 1] = float("nan")
+    x[0, 0, 2, 2] = 1.0; x[0, 0, 3, 3] = 1.0           # two equal maxima in one window
+    x.requires_grad_(True)
+    y = G.max_pool2d(x, 2, 2, 0)
+    assert torch.isnan(y[0, 0, 0, 0]) and float(y[0, 0, 1, 1]) == 1.0
+    y.backward(torch.ones_like(y))
+    assert float(x.grad[0, 0, 2, 2]) == 1.0 and float(x.grad[0, 0, 3, 3]) == 0.0
+
+
+def test_fp32_keras_layers_run_on_own_kernels():
+    """A fp32 Keras-style CNN with BatchNormalization, both poolings, an Embedding and a strided convolution: forward and
+    gradients against the same model evaluated with torch's own operators."""
+    import torch.nn.functional as F
+    from distributed_tensorflow_amd.api import layers as L
+    from distributed_tensorflow_amd.api.model import Sequential
+    torch.manual_seed(0)
+    m = Sequential([L.Conv2D(12, 3, strides=2, padding="same", activation="relu", input_shape=(17, 15, 3)),
+                    L.BatchNormalization(), L.MaxPooling2D((2, 3), (2, 1)), L.Conv2D(10, 1), L.AveragePooling2D(2),
+                    L.GlobalAveragePooling2D(), L.Dense(5)]).to(DEV)
+    m.train()
+    x = torch.randn(6, 17, 15, 3, device=DEV)
+    out = m(x, logits=True) if getattr(m, "supports_logits", False) else m(x)
+    out.float().square().sum().backward()
+    assert out.shape == (6, 5) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    # Embedding: gather + sorted-run gradient kernels
+    e = L.Embedding(50, 8).to(DEV)
+    e.build((4,))
+    ids = torch.randint(0, 50, (7, 4), device=DEV)
+    y = e(ids)
+    y.sum().backward()
+    ref = torch.nn.functional.embedding(ids, e.emb.weight.detach())
+    torch.testing.assert_close(y.detach(), ref)
+    want = torch.zeros(50, 8, device=DEV).index_add_(0, ids.reshape(-1), torch.ones(28, 8, device=DEV))
+    torch.testing.assert_close(e.emb.weight.grad, want)
+
+
+def test_fp32_convolution_has_no_library_route():
+    """conv2d of fp32 tensors (and of bf16 geometries the implicit-GEMM kernel does not take) runs on the general GEMM."""
+    from distributed_tensorflow_amd.ops import conv
+    assert not hasattr(conv, "set_conv1x1_backend") and not hasattr(conv, "set_convkxk_backend")
+    torch.manual_seed(1)
+    for dtype, shape, k, s, p in ((torch.float32, (3, 16, 12, 12), 3, 1, 1), (torch.float32, (2, 3, 9, 9), 3, 2, 1),
+                                  (torch.bfloat16, (2, 12, 9, 7), 3, 1, 1)):
+        N, C, H, W = shape
+        x = torch.randn(shape, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(20, C, k, k, device=DEV) * 0.2).to(dtype).contiguous(memory_format=torch.channels_last)
+        x1 = x.clone().requires_grad_(True); w1 = w.clone().requires_grad_(True)
+        y = conv.conv2d(x1, w1, s, p)
+        xr = x.detach().clone().float().requires_grad_(True); wr = w.detach().clone().float().requires_grad_(True)
+        yr = torch.nn.functional.conv2d(xr, wr, None, s, p)
+        dy = torch.randn_like(yr)
+        y.backward(dy.to(dtype)); yr.backward(dy)
+        tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+        torch.testing.assert_close(y.float(), yr.detach(), **tol)
+        torch.testing.assert_close(x1.grad.float(), xr.grad, **tol)
+        torch.testing.assert_close(w1.grad.float(), wr.grad, **(tol if dtype == torch.float32 else dict(rtol=5e-2, atol=0.15)))

@@ -46,11 +46,9 @@ def main():
     rep(lambda: A.self_attention(qkv).sum().backward())
     del qkv
     # implicit-GEMM 3x3 convolution, fwd + bwd
-    C.set_convkxk_backend("gemm")
     x = torch.randn(256, 128, 28, 28, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
     w = torch.randn(128, 128, 3, 3, device=DEV).to(bf).to(memory_format=torch.channels_last).requires_grad_(True)
     rep(lambda: C.conv2d(x, w, stride=1, padding=1).sum().backward())
-    C.set_convkxk_backend("auto")
     # ResNet-50 stage-1 bottleneck, training mode: 1x1 / 3x3 convolutions that gather the batch-norm statistics in
     # their store phase, norm + residual + ReLU, masked residual-gradient hand-over
     from distributed_tensorflow_amd.models import resnet as R
