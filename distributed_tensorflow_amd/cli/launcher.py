@@ -76,6 +76,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="default: sum for centralized (reference semantics), mean for decentralized")
     p.add_argument("--placement", choices=["colocated", "dedicated"], default="colocated",
                    help="async collective PS: shard owners are the workers | one extra server rank")
+    p.add_argument("--ps-data-plane", choices=["auto", "ipc", "p2p"], default="auto",
+                   help="async collective PS: how gradients and parameters move -- ipc: pull-only over HIP-IPC peer pointers "
+                        "(GPUs of one host, the default there), p2p: send-first transfers on pair communicators")
     p.add_argument("--algorithm", default="auto", help="custom strategy: auto|direct|ring|multiring|tree|oneshot on grouped send/recv, or "
                    "ipc|ipc-direct|ipc-fused|ipc-oneshot|ipc-ring|ipc-tree: kernels on HIP IPC mapped peer arenas (ipc-fused: one launch per bucket)")
     p.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
@@ -202,7 +205,8 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
         elif kind == "sync":
             st = ps.SyncPSStrategy(model, comm, cfg, optimizer=opt, metrics=metrics, apply=args.apply)
         elif kind == "async":
-            st = ps.AsyncPSStrategy(model, comm, cfg, optimizer=opt, metrics=metrics, placement=args.placement)
+            st = ps.AsyncPSStrategy(model, comm, cfg, optimizer=opt, metrics=metrics, placement=args.placement,
+                                    transport=getattr(args, "ps_data_plane", "auto"))
         else:
             raise ValueError(kind)
         if getattr(args, "load_weights", None):

@@ -187,10 +187,13 @@ class RcclComm(Comm):
         ready.record(cur)
         self._stream.wait_event(ready)
         _check(fn(ctypes.c_void_p(self._stream.cuda_stream)), "rccl enqueue")
-        for t in tensors:
-            t.record_stream(self._stream)
         done = torch.cuda.Event()
         done.record(self._stream)
+        # The tensors stay alive until the communication stream is done with them by REFERENCE (dropped here once
+        # their event has completed), not by record_stream: that makes the caching allocator poll an event per
+        # recorded block on every allocation, which cost a 100 GB training step a factor of five.
+        self._held = [h for h in getattr(self, "_held", ()) if not h[0].query()]
+        self._held.append((done, tensors))
         w = _Work(done, self.device)
         if async_op:
             return w

@@ -196,6 +196,22 @@ DTF_API int dtf_p2p_barrier(unsigned* const* flags, int world, int rank, unsigne
   return (int)hipGetLastError();
 }
 
+// Every XCD's L2 (blocks are dealt round-robin over the XCDs: 64 blocks reach each of the eight several times over)
+// and every CU's L1 they land on drop their copies of memory this device does not own. Launched in front of a kernel
+// that reads a peer's buffer with ordinary loads (the optimizer kernel reading a worker's gradient, a copy out of an
+// owner's reply slot): what that kernel then loads comes over the link, not out of a cache line left by last step's
+// read of the same addresses.
+namespace {
+__global__ __launch_bounds__(kWave) void p2p_acquire_kernel() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope
+}
+}  // namespace
+
+DTF_API int dtf_p2p_acquire(hipStream_t stream) {
+  hipLaunchKernelGGL(p2p_acquire_kernel, dim3(64), dim3(kWave), 0, stream);
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The one-hop all-reduce (reduce-scatter + all-gather) as ONE launch per rank instead of five (barrier, reduce,
 // barrier, gather, barrier): a resident grid (sized from the bucket, capped so that the backward pass keeps its CUs)

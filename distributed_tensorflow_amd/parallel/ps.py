@@ -304,9 +304,33 @@ class AsyncPSStrategy(Strategy):
     version after the apply): versions and staleness are host integers, and no thread ever parks a receive
     kernel on the GPU or reads a device tensor back to learn what to do next.
 
-    Data plane: one two-rank communicator per ordered (owner, worker) pair (RCCL send/recv over the pair's own
-    xGMI link; gloo on CPU). The worker posts its gradient shards and its parameter receives to ALL owners
-    before it waits for anything, so the seven links of a GPU work at once.
+    Data plane, ``transport``:
+
+    ``'ipc'`` (GPUs of one host; the default there): PULL ONLY over HIP-IPC peer pointers, and no device kernel ever
+    waits for anything outside its own GPU. Every rank maps every other rank's gradient arena and reply buffer. A
+    worker makes sure its gradient is in memory (one host wait on an event), then announces the push; the owner's
+    service thread launches the ordinary fused optimizer kernel with the worker's gradient shard -- read straight
+    through the peer pointer, over the pair's xGMI link -- as its gradient operand, copies the updated shard into the
+    reply slot it keeps for that worker, waits (host) for that copy and answers; the worker then copies the slot into
+    its own arena through the peer pointer. Nobody writes into another GPU's memory; a kernel that reads peer memory
+    is preceded by a system-scope acquire on every XCD (``dtf_p2p_acquire``), so no cache holds an older copy.
+    Both hand-offs are host-synchronous (an event wait plus a TCP frame: tens of microseconds against a step of
+    milliseconds), which is what makes the plane deadlock-free BY CONSTRUCTION: the only waits are host threads
+    waiting for their own device or for a frame, and a frame is always sent by a thread that waits for nothing
+    remote.
+
+    ``'p2p'``: one two-rank communicator per ordered (owner, worker) pair (RCCL send/recv; gloo on CPU), SENDS
+    FIRST: a worker posts ``send(gradient shard)`` to every owner (ascending rank) and only then announces; the
+    owner posts the matching receive when the announcement arrives, applies, posts ``send(parameters)`` and only then
+    answers; the worker posts the matching receive when the answer arrives (ascending rank). A transfer's second
+    half is therefore always posted by a host thread that is waiting for nothing on a device, and no kernel spans
+    another process's apply. A send / receive kernel still parks on its GPU until its partner runs, so on RCCL the
+    plane is only as safe as the hardware queues are independent: with ``placement='dedicated'`` every worker has at
+    most one transfer outstanding and the server's transfers each have their partner at the head of a worker's
+    queue -- no wait-for cycle exists whatever stream shares a hardware queue with whatever other. Colocated
+    owners on RCCL have both roles' kernels in the at most four hardware queues of a process, where a ring of
+    parked kernels (rank i's send behind rank i's receive) cannot be excluded: that combination is refused, the
+    IPC plane (one host) or the dedicated placement is what to use.
 
     ``model_lock`` (server.py:99-102) is an event chain on ONE apply stream per owner. Every apply -- a remote
     worker's and, colocated, the owner's own -- is enqueued on that stream, under a host lock that only fixes
@@ -319,10 +343,13 @@ class AsyncPSStrategy(Strategy):
     name = "async"
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None, metrics=None,
-                 placement: str = "colocated", max_staleness: int | None = None, master_addr: str | None = None):
+                 placement: str = "colocated", max_staleness: int | None = None, master_addr: str | None = None,
+                 transport: str = "auto"):
         cfg = cfg or TrainConfig()
         if placement not in ("colocated", "dedicated"):
             raise ValueError("placement must be 'colocated' or 'dedicated'")
+        if transport not in ("auto", "ipc", "p2p"):
+            raise ValueError("transport must be 'auto', 'ipc' or 'p2p'")
         W = comm.world
         self.placement = placement if W > 1 else "colocated"
         self.servers = list(range(W)) if self.placement == "colocated" else [0]
@@ -348,6 +375,11 @@ class AsyncPSStrategy(Strategy):
         self._calls = _RCCL_CALLS if comm.backend == "nccl" else _NoLock()
         self.pair: dict[tuple[int, int], Comm] = {}
         self._ctrl: dict[int, object] = {}    # worker side: owner rank -> control connection
+        self.transport = self._pick_transport(transport) if W > 1 else "p2p"
+        self._peers = None                    # IPC plane: comm.ipc.PeerGroup
+        self._grad_of: dict[int, torch.Tensor] = {}    # rank -> its gradient arena, through the peer pointer
+        self._reply_of: dict[int, torch.Tensor] = {}   # rank -> its reply buffer, through the peer pointer
+        self._reply_all = None
         self.ps_master = None
         if self.is_server:
             a, e = self.shard_of[r]
@@ -357,11 +389,66 @@ class AsyncPSStrategy(Strategy):
             self._connect(master_addr)
 
     # ---------------------------------------------------------------- set-up
+    def _pick_transport(self, want: str) -> str:
+        comm = self.comm
+        gpu = comm.device.type == "cuda"
+        if want == "ipc" and not gpu:
+            raise ValueError("transport='ipc' needs GPU devices")
+        if want == "auto":
+            want = "p2p"
+            if gpu:
+                import torch.distributed as dist
+                names = [None] * comm.world
+                dist.all_gather_object(names, socket.gethostname(), group=comm.group)
+                if len(set(names)) == 1 and os.environ.get("DTF_ASYNC_TRANSPORT", "ipc") == "ipc":
+                    want = "ipc"
+        if want == "p2p" and comm.backend == "nccl" and self.placement == "colocated":
+            raise ValueError("asynchronous parameter server: colocated shard owners over RCCL send/recv cannot be shown "
+                             "free of wait-for cycles between parked kernels; use the IPC plane (ranks on one host), "
+                             "--placement dedicated, or the TCP transport")
+        return want
+
+    def _peer_view(self, ptr: int, numel: int, dtype: torch.dtype) -> torch.Tensor:
+        """A tensor over ``numel`` elements at the raw device address ``ptr`` (peer memory mapped by HIP IPC)."""
+        esz = 4 if dtype == torch.float32 else 2
+        spec = {"shape": (numel,), "typestr": "<f4" if dtype == torch.float32 else "<u2", "data": (int(ptr), False),
+                "version": 2, "strides": None}
+        holder = type("_PeerMemory", (), {"__cuda_array_interface__": spec})()
+        t = torch.as_tensor(holder, device=self.comm.device)
+        if dtype == torch.bfloat16:
+            t = t.view(torch.bfloat16)
+        assert t.data_ptr() == ptr and t.numel() * esz == numel * esz
+        return t
+
+    def _connect_ipc(self) -> None:
+        """Maps every rank's gradient arena and reply buffer into this process (collective)."""
+        from ..comm.ipc import PeerGroup
+        comm, r, f = self.comm, self.comm.rank, self.flat
+        self._peers = PeerGroup(comm)
+        n = f.total // len(self.servers)
+        # reply slot of worker w at an owner: [w * n, (w + 1) * n) of the owner's buffer (fp32 shard snapshots)
+        self._reply_all = torch.zeros(comm.world * n if self.is_server else 64, dtype=torch.float32, device=comm.device)
+        kg = self._peers.register(f.grad)
+        kr = self._peers.register(self._reply_all)
+        gp, rp = self._peers._registered[kg][0], self._peers._registered[kr][0]
+        for j in range(comm.world):
+            self._grad_of[j] = f.grad if j == r else self._peer_view(gp[j], f.total, f.grad.dtype)
+            if j in self.servers:
+                self._reply_of[j] = self._reply_all if j == r else self._peer_view(rp[j], comm.world * n, torch.float32)
+
+    def _acquire(self) -> None:
+        """Before a kernel that reads peer memory: every XCD drops its cached copies of memory it does not own."""
+        from ..ops import _lib
+        _lib.check(_lib.kernels().dtf_p2p_acquire(_lib.stream_ptr(self.comm.device)), "p2p acquire")
+
     def _connect(self, master_addr) -> None:
         from ..comm import tcp
         comm, r, dev = self.comm, self.comm.rank, self.comm.device
         W = comm.world
         pairs = [(s, w) for s in self.servers for w in self.workers if s != w]
+        if self.transport == "ipc":
+            self._connect_ipc()
+            pairs = []
         # data plane: creation is collective on the parent group, in one order on every rank
         for s, w in pairs:
             c = comm.subgroup([s, w])
@@ -432,6 +519,8 @@ class AsyncPSStrategy(Strategy):
         receive -> apply -> reply on the apply stream -- the body of the reference's ``Server.run`` loop
         (reference centralized/server.py:62-105)."""
         try:
+            if self.transport == "ipc":
+                return self._serve_ipc(worker, conn)
             r = self.comm.rank
             c = self.pair[(r, worker)]
             peer = 1 - c.rank
@@ -448,7 +537,8 @@ class AsyncPSStrategy(Strategy):
                     raise RuntimeError(f"asynchronous parameter server: unknown control message {kind}")
                 copied = None
                 with self.lock, self._stream_ctx():
-                    # the worker posted its send before it announced the push: this wait is bounded
+                    # the worker posted its send before it announced the push: the receive is the transfer's second
+                    # half and completes without anybody's further help
                     with self._calls:
                         works = c.exchange([], [(grad, peer)])
                     for w_ in works:
@@ -459,18 +549,43 @@ class AsyncPSStrategy(Strategy):
                         copied = torch.cuda.Event()
                         copied.record()
                 # the reply leaves outside the lock (its buffer belongs to this thread): a worker that is slow to
-                # take it delays nobody else's apply
+                # take it delays nobody else's apply. The send is posted BEFORE the answer: the worker posts the
+                # matching receive when the answer arrives
                 with (torch.cuda.stream(send_stream) if send_stream is not None else _NoLock()):
                     if copied is not None:
                         send_stream.wait_event(copied)
                     with self._calls:
                         works = c.exchange([(reply, peer)], [])
-                    for w_ in works:
-                        w_.wait()
                 conn.send(_K_REPLY, {"version": ver})
+                for w_ in works:
+                    w_.wait()
             conn.close()
         except BaseException as ex:  # surfaced by join_servers()
             self._errors.append(ex)
+
+    def _serve_ipc(self, worker: int, conn) -> None:
+        """IPC plane: the optimizer kernel reads the worker's gradient shard through the peer pointer; the updated
+        shard is copied into this worker's reply slot; the answer leaves when that copy is in memory."""
+        r = self.comm.rank
+        a, e = self.shard_of[r]
+        n = e - a
+        slot = self._reply_all[worker * n:(worker + 1) * n]
+        grad = self._grad_of[worker][a:e]
+        while True:
+            kind, meta, _ = conn.recv()
+            if kind == _K_END:
+                break
+            if kind != _K_TRAIN:
+                raise RuntimeError(f"asynchronous parameter server: unknown control message {kind}")
+            with self.lock, self._stream_ctx():
+                self._acquire()
+                ver = self._apply(grad, int(meta["used"]))
+                slot.copy_(self.ps_master)
+                done = torch.cuda.Event()
+                done.record()
+            done.synchronize()            # outside the lock: the next apply is already being enqueued
+            conn.send(_K_REPLY, {"version": ver})
+        conn.close()
 
     # ---------------------------------------------------------------- worker
     def train_step(self, x, y):
@@ -488,15 +603,22 @@ class AsyncPSStrategy(Strategy):
         f = self.flat
         r = self.comm.rank
         dev = self.comm.device
-        remote = [s for s in self.servers if s != r]
-        # post every transfer (gradient out, parameters in; nothing here waits), then announce the pushes: all
-        # owners, and all links, work at once
+        remote = sorted(s for s in self.servers if s != r)
+        ipc = self.transport == "ipc"
         works = []
-        for s in remote:
-            a, e = self.shard_of[s]
-            c = self.pair[(s, r)]
-            with self._calls:
-                works += c.exchange([(f.grad[a:e], 1 - c.rank)], [(f.master[a:e], 1 - c.rank)])
+        if ipc:
+            # the owners read the gradient where it lies: it must BE in memory before the announcement leaves
+            ready_host = torch.cuda.Event()
+            ready_host.record()
+            ready_host.synchronize()
+        else:
+            # first halves: one send per owner, ascending rank, all posted before anything is announced, so that all
+            # owners -- and all links -- work at once
+            for s in remote:
+                a, e = self.shard_of[s]
+                c = self.pair[(s, r)]
+                with self._calls:
+                    works += c.exchange([(f.grad[a:e], 1 - c.rank)], [])
         for s in remote:
             self._ctrl[s].send(_K_TRAIN, {"used": self._versions_seen[s]})
         if r in self.shard_of:
@@ -516,11 +638,21 @@ class AsyncPSStrategy(Strategy):
                     applied.record()
             if applied is not None:
                 torch.cuda.current_stream(dev).wait_event(applied)
-        for s in remote:
+        for s in remote:                      # ascending rank: the order the receives are posted in is fixed
             kind, meta, _ = self._ctrl[s].recv()
             if kind != _K_REPLY:
                 raise RuntimeError("asynchronous parameter server: unexpected reply on the control connection")
             self._versions_seen[s] = int(meta["version"])
+            a, e = self.shard_of[s]
+            if ipc:
+                # the owner's copy into this worker's slot is in memory (it waited for it): pull it
+                n = e - a
+                self._acquire()
+                f.master[a:e].copy_(self._reply_of[s][r * n:(r + 1) * n])
+            else:
+                c = self.pair[(s, r)]
+                with self._calls:
+                    works += c.exchange([], [(f.master[a:e], 1 - c.rank)])
         for w_ in works:
             w_.wait()
         f.refresh_shadow()
@@ -545,6 +677,11 @@ class AsyncPSStrategy(Strategy):
                 c.close()
             self._ctrl = {}
         self.join_servers()
+        if self._peers is not None:
+            self.comm.barrier()            # nobody unmaps a buffer that a peer's last pull may still read
+            self._grad_of, self._reply_of = {}, {}
+            self._peers.close()
+            self._peers = None
         # final model = the owners' shards
         if self.ps_master is not None:
             a, e = self.shard_of[r]

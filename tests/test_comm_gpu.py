@@ -363,16 +363,20 @@ def test_collective_strategies_two_ranks_on_one_gpu(kind, two_rank_results):
         assert np.allclose(got[0]["w"], w_ref, atol=3e-5, rtol=1e-4), float(np.abs(got[0]["w"] - w_ref).max())
 
 
-def test_async_ps_loses_no_update_with_three_service_threads_per_owner_on_the_gpu():
-    """Four ranks share the GPU (gloo carries the tensors): every owner serves three workers from three host threads
-    that enqueue onto its one apply stream, next to the owner's own applies. Plain SGD with a power-of-two learning
-    rate on integer gradients is exact in fp32, so after 200 applies per shard the parameters must equal
-    init - lr * sum(gradients) bit for bit; a lost update, a doubled one or a torn reply would show."""
+@pytest.mark.parametrize("transport,world", [("ipc", 4), ("ipc", 8), ("p2p", 4)])
+def test_async_ps_loses_no_update_with_several_service_threads_per_owner_on_the_gpu(transport, world):
+    """Four / eight ranks share the GPU: every owner serves the other ranks from one host thread each, all enqueueing
+    onto its one apply stream next to the owner's own applies. ``ipc``: the optimizer kernel reads each worker's
+    gradient through the HIP-IPC peer pointer and the workers pull the replies the same way (no transfer kernel
+    anywhere); ``p2p``: send-first transfers on gloo. Plain SGD with a power-of-two learning rate on integer gradients
+    is exact in fp32, so after world * steps applies per shard the parameters must equal init - lr * sum(gradients)
+    bit for bit; a lost update, a doubled one, a torn reply or a stale cached read of peer memory would show."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_distributed_cpu import run_exact_async
-    world, steps = 4, 50
-    got = run_exact_async(world, "cuda:0", steps)
+    steps = 50 if world == 4 else 25
+    got = run_exact_async(world, "cuda:0", steps, transport)
     for r in range(world):
         assert "error" not in got[r], got[r].get("error")
+        assert got[r]["transport"] == transport
         assert got[r]["applies"] == world * steps
         assert got[r]["equal"], got[r]

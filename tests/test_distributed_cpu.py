@@ -408,7 +408,7 @@ def test_verify_replicas_detects_a_diverged_rank_on_every_rank(kind):
 
 
 # --------------------------------------------------------------------------- async PS: no lost update
-def _exact_async_worker(rank, world, cell, q, device, steps):
+def _exact_async_worker(rank, world, cell, q, device, steps, transport="auto"):
     """Pushes integer-valued gradients through the asynchronous parameter server with plain SGD and a power-of-two
     learning rate: every sum is exact in fp32 whatever the order of the applies, so the final parameters must equal
     init - lr * (sum of all gradients) bit for bit. A lost or doubled update, or a torn reply, changes them."""
@@ -427,7 +427,8 @@ def _exact_async_worker(rank, world, cell, q, device, steps):
         torch.manual_seed(0)
         lr = 2.0 ** -10
         st = ps.AsyncPSStrategy(reference_mlp(dropout=0.0), comm, TrainConfig(seed=0),
-                                optimizer=SGD(learning_rate=lr, momentum=0.0))
+                                optimizer=SGD(learning_rate=lr, momentum=0.0), transport=transport)
+        plane = st.transport
         f = st.flat
         n = f.total
         # parameters on a 2^-10 grid, small: every intermediate value is exactly representable
@@ -451,19 +452,21 @@ def _exact_async_worker(rank, world, cell, q, device, steps):
         want = init - lr * total
         got = f.master.cpu()
         q.put((rank, {"equal": bool(torch.equal(got, want)), "maxdiff": float((got - want).abs().max()),
-                      "applies": len(st.staleness_log), "max_staleness": max(st.staleness_log, default=0)}))
+                      "applies": len(st.staleness_log), "max_staleness": max(st.staleness_log, default=0),
+                      "transport": plane}))
         comm.barrier()
         comm.shutdown()
     except Exception as e:  # pragma: no cover
         q.put((rank, {"error": f"{e}\n{traceback.format_exc()}"}))
 
 
-def run_exact_async(world, device, steps):
+def run_exact_async(world, device, steps, transport="auto"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     cell = ctx.Value("i", 0)
-    procs = [ctx.Process(target=_exact_async_worker, args=(r, world, cell, q, device, steps)) for r in range(world)]
+    procs = [ctx.Process(target=_exact_async_worker, args=(r, world, cell, q, device, steps, transport))
+             for r in range(world)]
     for p in procs:
         p.start()
     got = {}
