@@ -344,7 +344,7 @@ class AsyncPSStrategy(Strategy):
 
     def __init__(self, model, comm: Comm, cfg: TrainConfig | None = None, optimizer=None, metrics=None,
                  placement: str = "colocated", max_staleness: int | None = None, master_addr: str | None = None,
-                 transport: str = "auto"):
+                 transport: str = "auto", staleness_lr: bool | None = None):
         cfg = cfg or TrainConfig()
         if placement not in ("colocated", "dedicated"):
             raise ValueError("placement must be 'colocated' or 'dedicated'")
@@ -364,6 +364,15 @@ class AsyncPSStrategy(Strategy):
         self.is_server = r in self.servers
         self.is_worker = r in self.workers
         self.max_staleness = max_staleness
+        # Staleness-aware step size: a gradient computed on parameters that are k applies old is applied with
+        # lr / (1 + k). With N workers in step every gradient is N - 1 applies old, so a round of N applies moves
+        # the parameters like ONE step on the averaged gradient; without it (the reference's behaviour, server.py:
+        # 98-102: every gradient at the full rate) a round is N full steps and an 8-worker run on a task with label
+        # noise ends 50 points below all-reduce (profiles/convergence_strategies_v2.txt). DTF_ASYNC_STALENESS_LR=0
+        # or staleness_lr=False restores the reference's rule.
+        if staleness_lr is None:
+            staleness_lr = os.environ.get("DTF_ASYNC_STALENESS_LR", "1") != "0"
+        self.staleness_lr = bool(staleness_lr)
         self.broadcast_initial(0)
         self.lock = threading.Lock()          # the reference's model_lock: fixes the enqueue order of applies
         self.version = 0                      # gradient applications enqueued on this shard so far
@@ -385,6 +394,7 @@ class AsyncPSStrategy(Strategy):
             a, e = self.shard_of[r]
             self.ps_master = self.flat.master[a:e].clone()     # the authoritative shard
             self.optimizer = FlatOptimizer(self.flat, optimizer, state_ranges=[(a, e)])
+            self._base_lr = float(self.optimizer.spec.learning_rate)
         if W > 1:
             self._connect(master_addr)
 
@@ -509,7 +519,11 @@ class AsyncPSStrategy(Strategy):
         """One optimizer step on the authoritative shard; the caller holds ``self.lock`` and has made the apply
         stream current."""
         a, e = self.shard_of[self.comm.rank]
-        self.staleness_log.append(self.version - version_used)
+        stale = max(0, self.version - version_used)
+        self.staleness_log.append(stale)
+        if self.staleness_lr:
+            # (a device-resident scalar: the write is ordered on the apply stream like the kernel that reads it)
+            self.optimizer.set_lr(self._base_lr / (1.0 + stale))
         self.optimizer.step([(a, e)], grad=_Shifted(grad_shard, -a), params=_Shifted(self.ps_master, -a))
         self.version += 1
         return self.version

@@ -87,6 +87,7 @@ class _ServerState:
         self.elapsed = None
         self.ended = 0
         self.staleness: list[int] = []
+        self.staleness_lr = os.environ.get("DTF_ASYNC_STALENESS_LR", "1") != "0"
         self.step_latency: list[float] = []
         self.errors: list[BaseException] = []
         self.steps_by_worker: dict[int, int] = {}      # worker index -> steps the server has applied for it
@@ -222,7 +223,10 @@ class _ServiceThread(threading.Thread):
                         reply = st.snapshot
                     else:
                         with st.lock:
-                            st.staleness.append(st.version - int(meta.get("version", st.version)))
+                            stale = max(0, st.version - int(meta.get("version", st.version)))
+                            st.staleness.append(stale)
+                            if st.staleness_lr:       # lr / (1 + staleness): see parallel/ps.py AsyncPSStrategy
+                                self.opt.set_lr(float(self.opt.spec.learning_rate) / (1.0 + stale))
                             self.opt.step(grad=g)
                             st.version += 1
                             st.count_step(self.index)
@@ -323,7 +327,7 @@ def start(sync_mode, model_fn, dataset_fn, n_nodes, optimizer=None, supervisor_a
         replica.model.save_weights(save_weights)
     res = {"ok": True, "elapsed": st.elapsed, "versions": st.version, "departed_workers": len(st.errors),
            "resumed": bool(resumed), "checkpoints_written": st.checkpoints_written,
-           "mean_staleness": sum(st.staleness) / max(1, len(st.staleness)),
+           "mean_staleness": sum(st.staleness) / max(1, len(st.staleness)), "max_staleness": max(st.staleness, default=0),
            "ps_step_latency_ms": 1e3 * sum(st.step_latency) / max(1, len(st.step_latency))}
     if evaluate:
         replica.flat.refresh_shadow()

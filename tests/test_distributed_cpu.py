@@ -427,7 +427,8 @@ def _exact_async_worker(rank, world, cell, q, device, steps, transport="auto"):
         torch.manual_seed(0)
         lr = 2.0 ** -10
         st = ps.AsyncPSStrategy(reference_mlp(dropout=0.0), comm, TrainConfig(seed=0),
-                                optimizer=SGD(learning_rate=lr, momentum=0.0), transport=transport)
+                                optimizer=SGD(learning_rate=lr, momentum=0.0), transport=transport,
+                                staleness_lr=False)      # every gradient at the full rate: the sum below is exact
         plane = st.transport
         f = st.flat
         n = f.total
