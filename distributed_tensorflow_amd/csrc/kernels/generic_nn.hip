@@ -75,7 +75,8 @@ __global__ __launch_bounds__(kBlock) void gbn_partial_kernel(const T* __restrict
   }
 }
 
-// One thread per channel: partial rows summed in row order.
+// 32 channels per block; the partial rows of a channel are summed by 8 lanes with four loads in flight each and
+// combined in a fixed order (dtf_common.h partials_col_sum): hundreds of rows summed by one thread is latency bound.
 __global__ __launch_bounds__(kBlock) void gbn_finalize_fwd_kernel(const float* __restrict__ part, int P,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float* run_mean,
@@ -83,10 +84,12 @@ __global__ __launch_bounds__(kBlock) void gbn_finalize_fwd_kernel(const float* _
                                                                   float* __restrict__ invstd, float* __restrict__ scale,
                                                                   float* __restrict__ shift, long long M, int C, float eps,
                                                                   float momentum) {
-  const int c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= C) return;
   float s0 = 0.f, s1 = 0.f;
-  for (int p = 0; p < P; ++p) { s0 += part[((long long)p * 2) * C + c]; s1 += part[((long long)p * 2 + 1) * C + c]; }
+  const bool own = partials_col_sum(part, P, 2LL * C, C, s0);
+  __syncthreads();
+  partials_col_sum(part + C, P, 2LL * C, C, s1);
+  if (!own) return;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   const float inv_m = 1.f / (float)M;
   const float mu = s0 * inv_m;
   const float var = fmaxf(s1 * inv_m - mu * mu, 0.f);
@@ -110,10 +113,12 @@ __global__ __launch_bounds__(kBlock) void gbn_finalize_bwd_kernel(const float* _
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                   float* __restrict__ cA, float* __restrict__ cK,
                                                                   float* __restrict__ c0, long long M, int C) {
-  const int c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= C) return;
   float s0 = 0.f, s1 = 0.f;
-  for (int p = 0; p < P; ++p) { s0 += part[((long long)p * 2) * C + c]; s1 += part[((long long)p * 2 + 1) * C + c]; }
+  const bool own = partials_col_sum(part, P, 2LL * C, C, s0);
+  __syncthreads();
+  partials_col_sum(part + C, P, 2LL * C, C, s1);
+  if (!own) return;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   dbeta[c] = s0;
   dgamma[c] = s1;
   const float inv_m = 1.f / (float)M;
@@ -286,7 +291,7 @@ DTF_API int dtf_gbn_fwd_stats(const void* x, int dtype, long long M, int C, cons
   else
     hipLaunchKernelGGL((gbn_partial_kernel<unsigned short, 0>), grid, dim3(kBlock), 0, stream, (const unsigned short*)x,
                        nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0);
-  hipLaunchKernelGGL(gbn_finalize_fwd_kernel, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, workspace, P,
+  hipLaunchKernelGGL(gbn_finalize_fwd_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, workspace, P,
                      gamma, beta, run_mean, run_var, mean, invstd, scale, shift, M, C, eps, momentum);
   return (int)hipGetLastError();
 }
@@ -322,7 +327,7 @@ DTF_API int dtf_gbn_bwd(const void* dy, const void* x, const void* y, void* dx, 
     hipLaunchKernelGGL((gbn_partial_kernel<unsigned short, 1>), grid, dim3(kBlock), 0, stream, (const unsigned short*)x,
                        (const unsigned short*)dy, (const unsigned short*)y, mean, invstd, workspace, M, C, relu);
   float *cA = coef, *cK = coef + C, *c0 = coef + 2 * C;
-  hipLaunchKernelGGL(gbn_finalize_bwd_kernel, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, workspace, P,
+  hipLaunchKernelGGL(gbn_finalize_bwd_kernel, dim3((C + 31) / 32), dim3(kBlock), 0, stream, workspace, P,
                      gamma, invstd, dgamma, dbeta, cA, cK, c0, M, C);
   const long long total = M * C;
   const dim3 g2(grid_stream(total, kBlock));
