@@ -25,6 +25,19 @@ namespace {
 constexpr int TM = 64, TN = 64, TK = 16;
 constexpr int kPitch = 80;      // floats per k-row of an LDS image
 
+// Convolution as an implicit product: one operand is not a matrix in memory but the patch matrix of an NHWC image,
+// gathered element by element while it is staged (zero outside the image), so that no im2col buffer -- KH * KW times
+// the activation -- is ever written or read:
+//   GM 1 (forward)          A(m, q)  = x[n][oh * SH - PT + kh][ow * SW - PL + kw][c],   m = (n, oh, ow), q = (kh, kw, c)
+//   GM 2 (weight gradient)  B(m, q)  = the same element with the roles swapped: the contraction runs over the pixels m
+//   GM 3 (data gradient)    A(p, q') = dy[n][(ih + PT - kh) / SH][(iw + PL - kw) / SW][ko] where the divisions are exact
+//                           and in range, p = (n, ih, iw), q' = (kh, kw, ko); B is the weight as [(kh, kw, ko), c]
+struct ConvGather {
+  int H, W, C;        // the gathered image: height, width, channels (GM 3: the OUTPUT gradient's OH, OW, K)
+  int OH, OW;         // the other side's spatial size (GM 1, 2: output; GM 3: the input image's H, W)
+  int KH, KW, SH, SW, PT, PL;
+};
+
 struct AnyArgs {
   const void* A;
   const void* B;
@@ -35,6 +48,7 @@ struct AnyArgs {
   int k_per_split, splits;
   int bias_dtype;     // 0 fp32, 1 bf16
   int act;            // 0 none, 1 relu, 2 gelu (erf)
+  ConvGather cg;
 };
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
@@ -70,7 +84,63 @@ __device__ __forceinline__ void stage(float* lds, const T* base, long long sr, l
   }
 }
 
-template <typename TA, typename TB, typename TC>
+// Element offset of patch entry (pixel, q) in the gathered image, or -1 for padding. DG = false: forward geometry
+// (pixel indexes the output), DG = true: data-gradient geometry (pixel indexes the input, the image is dy).
+template <bool DG>
+__device__ __forceinline__ long long patch_offset(const ConvGather& c, int n, int a, int b, int q) {
+  // (a, b): DG false: (oh * SH - PT, ow * SW - PL); DG true: (ih + PT, iw + PL) -- decoded once per row by the caller
+  const int ch = q % c.C, tap = q / c.C;
+  const int kh = tap / c.KW, kw = tap - kh * c.KW;
+  int y, x;
+  if (!DG) {
+    y = a + kh; x = b + kw;
+  } else {
+    const int th = a - kh, tw = b - kw;
+    if (th < 0 || tw < 0 || th % c.SH || tw % c.SW) return -1;
+    y = th / c.SH; x = tw / c.SW;
+  }
+  if ((unsigned)y >= (unsigned)c.H || (unsigned)x >= (unsigned)c.W) return -1;
+  return (((long long)n * c.H + y) * c.W + x) * c.C + ch;
+}
+
+// Rows of the tile are pixels, k runs over q (channels fastest in memory): 16 consecutive threads walk q.
+// pix[i] = {n, a, b} of row (t >> 4) + 16 i, decoded once before the k-loop (n < 0: row past the end).
+template <typename T, bool DG>
+__device__ __forceinline__ void stage_patch_rows(float* lds, const T* base, const ConvGather& c, const int (&pix)[4][3],
+                                                 int k0, int kend) {
+  const int t = threadIdx.x, k = t & 15;
+  const bool kok = k0 + k < kend;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (t >> 4) + 16 * i;
+    long long off = -1;
+    if (kok && pix[i][0] >= 0) off = patch_offset<DG>(c, pix[i][0], pix[i][1], pix[i][2], k0 + k);
+    lds[k * kPitch + r] = off >= 0 ? ldf<T>(base + off) : 0.f;
+  }
+}
+
+// Rows of the tile are patch entries q (fixed per thread, 64 consecutive threads walk them: their tap (kh, kw) and
+// channel are decoded once, before the k-loop), k runs over the pixels (the same pixel for a whole wave).
+template <typename T>
+__device__ __forceinline__ void stage_patch_cols(float* lds, const T* base, const ConvGather& c, int kh, int kw, int ch,
+                                                 bool qok, int k0, int kend) {
+  const int t = threadIdx.x, r = t & 63;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = (t >> 6) + 4 * i;
+    const int m = k0 + k;
+    long long off = -1;
+    if (qok && m < kend) {
+      const int ow = m % c.OW, r2 = m / c.OW;
+      const int oh = r2 % c.OH, n = r2 / c.OH;
+      const int y = oh * c.SH - c.PT + kh, x = ow * c.SW - c.PL + kw;
+      if ((unsigned)y < (unsigned)c.H && (unsigned)x < (unsigned)c.W) off = (((long long)n * c.H + y) * c.W + x) * c.C + ch;
+    }
+    lds[k * kPitch + r] = off >= 0 ? ldf<T>(base + off) : 0.f;
+  }
+}
+
+template <typename TA, typename TB, typename TC, int GM = 0>
 __global__ __launch_bounds__(256) void gemm_any_kernel(AnyArgs g) {
   __shared__ float As[TK * kPitch];
   __shared__ float Bs[TK * kPitch];
@@ -90,9 +160,39 @@ __global__ __launch_bounds__(256) void gemm_any_kernel(AnyArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // gathered operands: what does not change along k is decoded once
+  int pix[4][3];
+  if (GM == 1 || GM == 3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + (threadIdx.x >> 4) + 16 * i;
+      if (m < g.M) {
+        // (OH, OW) is the grid the ROW index runs over: the output pixels (GM 1), the input pixels (GM 3)
+        const int x = m % g.cg.OW, r2 = m / g.cg.OW;
+        const int y = r2 % g.cg.OH;
+        pix[i][0] = r2 / g.cg.OH;
+        pix[i][1] = GM == 1 ? y * g.cg.SH - g.cg.PT : y + g.cg.PT;
+        pix[i][2] = GM == 1 ? x * g.cg.SW - g.cg.PL : x + g.cg.PL;
+      } else {
+        pix[i][0] = -1; pix[i][1] = pix[i][2] = 0;
+      }
+    }
+  }
+  const int qcol = n0 + (threadIdx.x & 63);
+  int q_kh = 0, q_kw = 0, q_ch = 0;
+  if (GM == 2) {
+    const int tap = qcol / g.cg.C;
+    q_ch = qcol - tap * g.cg.C;
+    q_kh = tap / g.cg.KW;
+    q_kw = tap - q_kh * g.cg.KW;
+  }
+
   for (int k0 = kbeg; k0 < kend; k0 += TK) {
-    stage<TA>(As, A, g.sam, g.sak, m0, k0, g.M, kend);
-    stage<TB>(Bs, B, g.sbn, g.sbk, n0, k0, g.N, kend);
+    if (GM == 1) stage_patch_rows<TA, false>(As, A, g.cg, pix, k0, kend);
+    else if (GM == 3) stage_patch_rows<TA, true>(As, A, g.cg, pix, k0, kend);
+    else stage<TA>(As, A, g.sam, g.sak, m0, k0, g.M, kend);
+    if (GM == 2) stage_patch_cols<TB>(Bs, B, g.cg, q_kh, q_kw, q_ch, qcol < g.N, k0, kend);
+    else stage<TB>(Bs, B, g.sbn, g.sbk, n0, k0, g.N, kend);
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < TK; kk += 4) {
@@ -173,14 +273,24 @@ void launch_c(const AnyArgs& g, int c_dtype, dim3 grid, hipStream_t stream) {
   else hipLaunchKernelGGL((gemm_any_kernel<TA, TB, unsigned short>), grid, dim3(256), 0, stream, g);
 }
 
+// gathered variants: both operands of one element type (a convolution's image, gradient and weight share it)
+template <typename T, int GM>
+void launch_gather(const AnyArgs& g, int c_dtype, dim3 grid, hipStream_t stream) {
+  if (c_dtype == 0 || g.splits > 1)
+    hipLaunchKernelGGL((gemm_any_kernel<T, T, float, GM>), grid, dim3(256), 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_any_kernel<T, T, unsigned short, GM>), grid, dim3(256), 0, stream, g);
+}
+
 }  // namespace
 
 // dtype codes: 0 = fp32, 1 = bf16. Strides in elements. workspace: fp32, >= splits * M * N floats when splits > 1.
-DTF_API int dtf_gemm_any(const void* A, int a_dtype, long long sam, long long sak, const void* B, int b_dtype,
-                         long long sbk, long long sbn, void* C, int c_dtype, long long ldc, const void* bias,
-                         int bias_dtype, int act, int M, int N, int K, int splits, void* workspace,
-                         hipStream_t stream) {
+static int gemm_any_launch(int gm, const ConvGather* cg, const void* A, int a_dtype, long long sam, long long sak,
+                           const void* B, int b_dtype, long long sbk, long long sbn, void* C, int c_dtype, long long ldc,
+                           const void* bias, int bias_dtype, int act, int M, int N, int K, int splits, void* workspace,
+                           hipStream_t stream) {
   if (M <= 0 || N <= 0) return 0;
+  if (gm != 0 && (a_dtype != b_dtype || !cg)) return -1;
   if (!A || !B || !C || K < 0 || (unsigned)a_dtype > 1u || (unsigned)b_dtype > 1u || (unsigned)c_dtype > 1u) return -1;
   if (splits < 1) splits = 1;
   int kps = ((K + splits - 1) / splits + TK - 1) / TK * TK;
@@ -191,9 +301,18 @@ DTF_API int dtf_gemm_any(const void* A, int a_dtype, long long sam, long long sa
   g.A = A; g.B = B; g.C = splits > 1 ? workspace : C; g.bias = bias;
   g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K; g.k_per_split = kps; g.splits = splits; g.bias_dtype = bias_dtype; g.act = act;
+  if (cg) g.cg = *cg; else g.cg = ConvGather{};
   const dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, splits);
   if (grid.y > 65535u || grid.z > 65535u) return -2;
-  if (a_dtype == 0 && b_dtype == 0) launch_c<float, float>(g, c_dtype, grid, stream);
+  if (gm != 0) {
+#define LG(GM_)                                                                       \
+  do {                                                                                \
+    if (a_dtype == 0) launch_gather<float, GM_>(g, c_dtype, grid, stream);            \
+    else launch_gather<unsigned short, GM_>(g, c_dtype, grid, stream);                \
+  } while (0)
+    if (gm == 1) LG(1); else if (gm == 2) LG(2); else if (gm == 3) LG(3); else return -1;
+#undef LG
+  } else if (a_dtype == 0 && b_dtype == 0) launch_c<float, float>(g, c_dtype, grid, stream);
   else if (a_dtype == 1 && b_dtype == 1) launch_c<unsigned short, unsigned short>(g, c_dtype, grid, stream);
   else if (a_dtype == 0) launch_c<float, unsigned short>(g, c_dtype, grid, stream);
   else launch_c<unsigned short, float>(g, c_dtype, grid, stream);
@@ -207,6 +326,31 @@ DTF_API int dtf_gemm_any(const void* A, int a_dtype, long long sam, long long sa
                          (const float*)workspace, (unsigned short*)C, bias, bias_dtype, act, splits, M, N, ldc);
   }
   return (int)hipGetLastError();
+}
+
+DTF_API int dtf_gemm_any(const void* A, int a_dtype, long long sam, long long sak, const void* B, int b_dtype,
+                         long long sbk, long long sbn, void* C, int c_dtype, long long ldc, const void* bias,
+                         int bias_dtype, int act, int M, int N, int K, int splits, void* workspace,
+                         hipStream_t stream) {
+  return gemm_any_launch(0, nullptr, A, a_dtype, sam, sak, B, b_dtype, sbk, sbn, C, c_dtype, ldc, bias, bias_dtype, act,
+                         M, N, K, splits, workspace, stream);
+}
+
+// Convolution passes as implicit products (see ConvGather). `img` is the gathered NHWC tensor, `mat` the ordinary
+// matrix operand with its two strides (k stride, n stride for gm 1 / 3: the B matrix; m stride, k stride for gm 2: the
+// A matrix). geom = {H, W, C, OH, OW, KH, KW, SH, SW, PT, PL} as documented at ConvGather. M, N, K: the product's
+// sizes (gm 1: pixels x K_out x KH*KW*C; gm 2: K_out x KH*KW*C x pixels; gm 3: input pixels x C_in x KH*KW*K_out).
+DTF_API int dtf_gemm_any_conv(int gm, const void* img, const void* mat, int dtype, long long s0, long long s1,
+                              const int* geom, void* C, int c_dtype, long long ldc, const void* bias, int bias_dtype,
+                              int act, int M, int N, int K, int splits, void* workspace, hipStream_t stream) {
+  if (!geom || gm < 1 || gm > 3 || !img || !mat) return -1;
+  ConvGather cg = {geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6], geom[7], geom[8], geom[9], geom[10]};
+  if (cg.C <= 0 || cg.KW <= 0 || cg.SH <= 0 || cg.SW <= 0 || cg.OW <= 0 || cg.OH <= 0) return -1;
+  if (gm == 2)
+    return gemm_any_launch(2, &cg, mat, dtype, s0, s1, img, dtype, 0, 0, C, c_dtype, ldc, bias, bias_dtype, act, M, N, K,
+                           splits, workspace, stream);
+  return gemm_any_launch(gm, &cg, img, dtype, 0, 0, mat, dtype, s0, s1, C, c_dtype, ldc, bias, bias_dtype, act, M, N, K,
+                         splits, workspace, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

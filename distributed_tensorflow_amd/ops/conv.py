@@ -515,10 +515,10 @@ def conv2d_fork(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding: int 
 
 
 class _ConvAnyFn(torch.autograd.Function):
-    """Convolution as patch matrix x weight matrix on the general-purpose exact-fp32 MFMA GEMM: the GPU path of
-    fp32 layers and of geometries the implicit-GEMM kernel does not take (rectangular strides, odd channel counts
-    deeper in a network). im2col and its transpose are the framework's own gather kernels; the patch matrix is
-    rebuilt in the backward pass rather than kept."""
+    """Convolution on the general-purpose exact-fp32 MFMA GEMM: the GPU path of fp32 layers and of geometries the bf16
+    implicit-GEMM kernel does not take (rectangular strides, odd channel counts deeper in a network). All three passes
+    are IMPLICIT products (``ops.gemm_any.conv_product``): the kernel gathers the patch matrix from the NHWC image
+    while it stages the operand, so no im2col buffer -- KH * KW times the activation, per pass -- exists."""
 
     @staticmethod
     def forward(ctx, x, w, bias, sh, sw, pt, pl, OH, OW, activation):
@@ -526,33 +526,37 @@ class _ConvAnyFn(torch.autograd.Function):
         K, _, KH, KW = w.shape
         xn = x.permute(0, 2, 3, 1).contiguous()
         wm = w.permute(0, 2, 3, 1).reshape(K, KH * KW * C)
-        plain = KH == 1 and KW == 1 and sh == 1 and sw == 1 and pt == 0 and pl == 0
-        cols = xn.reshape(-1, C) if plain else _any.im2col(xn, KH, KW, sh, sw, pt, pl, OH, OW)
-        y = _any.matmul(cols, wm.t(), bias=bias, activation="relu" if activation == "relu" else None,
-                        out_dtype=x.dtype)
-        ctx.save_for_backward(xn, w, y if activation == "relu" else None)
-        ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, sh, sw, pt, pl, plain)
+        act = "relu" if activation == "relu" else None
+        y = _any.conv_product("fwd", xn, wm.t(), (H, W, C, OH, OW, KH, KW, sh, sw, pt, pl), N * OH * OW, K,
+                              KH * KW * C, bias=bias, activation=act, out_dtype=x.dtype)
+        ctx.save_for_backward(xn, w, y if act == "relu" else None)
+        ctx.geom = (N, C, H, W, K, KH, KW, OH, OW, sh, sw, pt, pl)
         ctx.bias_dtype = bias.dtype if bias is not None else None
         return y.view(N, OH, OW, K).permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
         xn, w, y_act = ctx.saved_tensors
-        N, C, H, W, K, KH, KW, OH, OW, sh, sw, pt, pl, plain = ctx.geom
+        N, C, H, W, K, KH, KW, OH, OW, sh, sw, pt, pl = ctx.geom
         g = gy.permute(0, 2, 3, 1).reshape(-1, K)
         if not g.is_contiguous():
             g = g.contiguous()
+        if g.dtype != xn.dtype:
+            g = g.to(xn.dtype)
         if y_act is not None:
             g = _any.ew_f32(0, g, y_act) if g.dtype == torch.float32 else _gemm.relu_bwd(g, y_act)
         gx = gw = gb = None
-        wm = w.permute(0, 2, 3, 1).reshape(K, KH * KW * C)
         if ctx.needs_input_grad[0]:
-            gcols = _any.matmul(g, wm, out_dtype=xn.dtype)
-            gxn = gcols.view(N, H, W, C) if plain else _any.col2im(gcols, (N, H, W, C), KH, KW, sh, sw, pt, pl, OH, OW)
-            gx = gxn.permute(0, 3, 1, 2)
+            # dx[(n, ih, iw), c] = sum over (kh, kw, ko) of dy at the output pixel that tap reads from, times w
+            wd = w.permute(2, 3, 0, 1).reshape(KH * KW * K, C)          # [(kh, kw, ko), c]; the weight is small
+            if not wd.is_contiguous():
+                wd = wd.contiguous()
+            gxn = _any.conv_product("dgrad", g.view(N, OH, OW, K), wd, (OH, OW, K, H, W, KH, KW, sh, sw, pt, pl),
+                                    N * H * W, C, KH * KW * K, out_dtype=xn.dtype)
+            gx = gxn.view(N, H, W, C).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            cols = xn.reshape(-1, C) if plain else _any.im2col(xn, KH, KW, sh, sw, pt, pl, OH, OW)
-            gw = _any.matmul(g.t(), cols, out_dtype=w.dtype).view(K, KH, KW, C).permute(0, 3, 1, 2)
+            gw = _any.conv_product("wgrad", xn, g.t(), (H, W, C, OH, OW, KH, KW, sh, sw, pt, pl), K, KH * KW * C,
+                                   N * OH * OW, out_dtype=w.dtype).view(K, KH, KW, C).permute(0, 3, 1, 2)
         if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
             gb = g.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
         return gx, gw, gb, None, None, None, None, None, None, None

@@ -68,6 +68,36 @@ def matmul(a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None, a
     return out
 
 
+def conv_product(mode: str, img: torch.Tensor, mat: torch.Tensor, geom: tuple, M: int, N: int, K: int,
+                 bias: torch.Tensor | None = None, activation: str | None = None,
+                 out_dtype: torch.dtype | None = None) -> torch.Tensor:
+    """One pass of a convolution as an IMPLICIT product: the patch matrix of the contiguous NHWC tensor ``img`` is
+    gathered while the kernel stages it, never written to memory.
+
+    ``mode='fwd'``:   ``[M = N*OH*OW, N = K_out] = patches(x) [M, K = KH*KW*C] @ mat [K, N]`` (``mat`` any strides)
+    ``mode='wgrad'``: ``[M = K_out, N = KH*KW*C] = mat [M, K = N*OH*OW] @ patches(x) [K, N]``
+    ``mode='dgrad'``: ``[M = N*H*W, N = C_in] = patches'(dy) [M, K = KH*KW*K_out] @ mat [K, N]`` with the transposed
+    patch geometry (``img`` = dy; ``mat`` = the weight as ``[(kh, kw, k_out), c_in]``)
+    ``geom`` = (H, W, C, OH, OW, KH, KW, SH, SW, PT, PL): the image's own size and channels first, then the other side's
+    spatial size (for 'dgrad' the image is dy, so H, W, C = OH, OW, K_out and OH, OW = the input's H, W)."""
+    gm = {"fwd": 1, "wgrad": 2, "dgrad": 3}[mode]
+    if not usable(img, mat) or img.dtype != mat.dtype or not img.is_contiguous() or mat.dim() != 2:
+        raise ValueError("gemm_any.conv_product: needs a contiguous NHWC image and a matrix of the same GPU float type")
+    out = torch.empty((M, N), dtype=out_dtype or img.dtype, device=img.device)
+    if bias is not None and (bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("gemm_any.conv_product: bias must be a contiguous [N] vector")
+    splits = _pick_splits(M, N, K)
+    ws = _workspace(img.device, splits * M * N) if splits > 1 else None
+    g = (ctypes.c_int * 11)(*[int(v) for v in geom])
+    rc = _lib.kernels().dtf_gemm_any_conv(
+        gm, _lib.ptr(img), _lib.ptr(mat), _lib.dtype_code(img.dtype), ctypes.c_longlong(mat.stride(0)),
+        ctypes.c_longlong(mat.stride(1)), g, _lib.ptr(out), _lib.dtype_code(out.dtype), ctypes.c_longlong(N),
+        _lib.ptr(bias), _lib.dtype_code(bias.dtype) if bias is not None else 0, _ACT[activation], M, N, K, splits,
+        _lib.ptr(ws), _lib.stream_ptr(img.device))
+    _lib.check(rc, "gemm_any_conv")
+    return out
+
+
 def im2col(x_nhwc: torch.Tensor, KH, KW, SH, SW, PT, PL, OH, OW) -> torch.Tensor:
     """``[N*OH*OW, KH*KW*C]`` patch matrix of a contiguous ``[N, H, W, C]`` image (zero padded)."""
     N, H, W, C = x_nhwc.shape
