@@ -62,12 +62,13 @@ class WideDeep(Model):
         B = ids.shape[0]
         wdt = self.out.weight.dtype
         dense = torch.nn.functional.pad(dense.to(wdt), (0, _pad8(self.n_dense) - self.n_dense))
-        emb = self.deep_emb(ids).to(wdt).reshape(B, -1)
+        plan = self.deep_emb.plan(ids)           # both tables are indexed by the same ids: one routing plan for the two
+        emb = self.deep_emb(ids, plan).to(wdt).reshape(B, -1)
         h = torch.cat([emb, dense], dim=1)
         for l in self.mlp:
             h = l(h)
         deep = self.out(h)[:, 0].float()
-        wide = self.wide_emb(ids).float().sum(dim=(1, 2)) + self.wide_dense(dense)[:, 0].float()
+        wide = self.wide_emb(ids, plan).float().sum(dim=(1, 2)) + self.wide_dense(dense)[:, 0].float()
         z = deep + wide
         return z if logits else torch.sigmoid(z)
 

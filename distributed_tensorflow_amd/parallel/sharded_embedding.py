@@ -56,15 +56,15 @@ def _all_to_all_v(comm: Comm, send: torch.Tensor, send_counts: list[int], recv_c
 
 class _Lookup(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, module, ids):
-        rows, plan = module._pull(ids)
+    def forward(ctx, anchor, module, ids, plan=None):
+        rows, plan = module._pull(ids, plan)
         ctx.module, ctx.plan = module, plan
         return rows
 
     @staticmethod
     def backward(ctx, g):
         ctx.module._push(g, ctx.plan)
-        return torch.zeros((), device=g.device), None, None
+        return torch.zeros((), device=g.device), None, None, None
 
 
 class ShardedEmbedding(nn.Module):
@@ -105,7 +105,12 @@ class ShardedEmbedding(nn.Module):
         self.rows_pulled = 0
 
     # ------------------------------------------------------------------ pull
-    def _pull(self, ids: torch.Tensor):
+    def plan(self, ids: torch.Tensor):
+        """Routing of one batch of ids: who owns which, in what order they travel, and the ids every owner has to
+        serve. It depends on the ids and the shard size only, so tables of the same height that are looked up with
+        the same ids (Wide&Deep's deep and wide tables) share ONE plan: one id exchange and ONE host read of the
+        per-owner counts per step instead of one per table (the variable-size all-to-all needs its split sizes on the
+        host; that read is the only host synchronisation of a lookup)."""
         comm, W = self.comm, self.comm.world
         flat = ids.reshape(-1).long()
         owner = torch.div(flat, self.rows_per_shard, rounding_mode="floor").clamp_(0, W - 1)
@@ -115,24 +120,32 @@ class ShardedEmbedding(nn.Module):
         if W > 1:
             recv_counts_t = torch.empty_like(send_counts)
             comm.all_to_all(recv_counts_t, send_counts)
-            sc, rc = send_counts.tolist(), recv_counts_t.tolist()
+            sc, rc = torch.stack([send_counts, recv_counts_t]).tolist()       # one device -> host read for both
         else:
             sc = rc = [flat.numel()]
         req = _all_to_all_v(comm, sorted_ids, sc, rc)                      # ids this shard must serve
-        rows = E._gather(self.table, req, row_base=self.row_base)          # [m, D]
-        got = _all_to_all_v(comm, rows, rc, sc)                            # rows for my ids, owner-sorted
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=order.device)
-        out = got.index_select(0, inv).view(*ids.shape, self.D)
-        self.rows_pulled += int(flat.numel())
-        return out, (order, sc, rc, req)
+        return (order, sc, rc, req, inv, self.rows_per_shard, tuple(ids.shape))
 
-    def forward(self, ids: torch.Tensor) -> torch.Tensor:
-        return _Lookup.apply(self._anchor, self, ids)
+    def _pull(self, ids: torch.Tensor, plan=None):
+        if plan is None:
+            plan = self.plan(ids)
+        order, sc, rc, req, inv, rps, shape = plan
+        if rps != self.rows_per_shard or shape != tuple(ids.shape):
+            raise ValueError("lookup plan was made for another table height or batch shape")
+        rows = E._gather(self.table, req, row_base=self.row_base)          # [m, D]
+        got = _all_to_all_v(self.comm, rows, rc, sc)                       # rows for my ids, owner-sorted
+        out = got.index_select(0, inv).view(*ids.shape, self.D)
+        self.rows_pulled += int(ids.numel())
+        return out, plan
+
+    def forward(self, ids: torch.Tensor, plan=None) -> torch.Tensor:
+        return _Lookup.apply(self._anchor, self, ids, plan)
 
     # ------------------------------------------------------------------ push
     def _push(self, g: torch.Tensor, plan) -> None:
-        order, sc, rc, req = plan
+        order, sc, rc, req = plan[:4]
         g2 = g.reshape(-1, self.D).float().index_select(0, order)          # owner-sorted gradients
         recv = _all_to_all_v(self.comm, g2, sc, rc)                        # gradients for the rows I own
         self._pending.append((req, recv))
