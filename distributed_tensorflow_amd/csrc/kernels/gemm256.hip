@@ -26,6 +26,7 @@
 // hardware-transposing ds_read_b64_tr_b16; the DMA source permutation is the XOR of that layout.
 // The reference trains its dense layers through TensorFlow's CPU MatMul (reference initializer.py:16-18).
 #include "dtf_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 using namespace dtf;
@@ -37,7 +38,8 @@ constexpr int kT256 = 512;
 constexpr int kHalfBytes = 128 * TK * 2;   // 16 KiB: 128 rows x 64 bf16
 constexpr int kBufBytes = 4 * kHalfBytes;  // A0 A1 B0 B1
 constexpr int kLds256 = 2 * kBufBytes;     // 128 KiB of operand buffers
-constexpr int kLdsAll = kLds256 + 8 * 4096;  // + 4 KiB of epilogue staging per wave = the CU's 160 KiB
+constexpr int kCusStagger = 256;
+constexpr int kLdsAll = kLds256;
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -60,7 +62,8 @@ struct G256Args {
   float* W;              // fp32 slabs [splits][M][N] when splits > 1
   int k_per_split;       // multiple of TK
   int splits;
-  long long* stamps;     // diagnostic: per workgroup 4 wall-clock stamps of its first tile (null = off)
+  long long* stamps;     // diagnostic: per output tile 4 wall-clock stamps (loop top, operands there, k-loop done, stores issued); null = off
+  int stagger;           // measurement hooks. > 0: 10 ns ticks between the start groups of the first round of workgroups; -1: no output stores
 };
 
 __device__ __forceinline__ int swz256(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -125,11 +128,22 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
   const int wr = wid >> 2, wc = wid & 3;
   const int fr = lane & 15, fq = lane >> 4;
 
-  // Persistent over output tiles: block b runs tiles b, b + gridDim.x, ... The DMA of the next tile's
-  // first K-tiles is issued BEFORE the epilogue of the current one (which stages through the 32 KiB of
-  // LDS the operand buffers leave free), so output stores and the next prologue's latency overlap.
+  // Persistent over output tiles: block b runs tiles b, b + gridDim.x, ... The DMA of the next tile's first two
+  // K-tiles is issued BEFORE the epilogue of the current one, so that the output stores (younger in the wave's
+  // in-order memory queue) can stay in flight under the next tile's first K-tiles.
   const int nwg = g.tiles_m * g.tiles_n;
-  const int split = blockIdx.y;
+  // Split-K launches use a flat grid over (split, tile) pairs in split-major order, cut into eight contiguous ranges,
+  // one per XCD (workgroup L is dispatched to XCD L % 8): the workgroups of one split read the same K-slab of both
+  // operands at the same time, and with a whole split on one XCD that slab crosses the fabric once instead of once
+  // per XCD that happens to hold some of the split's tiles.
+  int split = 0, flat_tile = -1;
+  if (g.splits > 1) {
+    const int total = nwg * g.splits, L = blockIdx.x;
+    const int xcd = L & 7, q8 = total >> 3, rem = total & 7;
+    const int w = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (L >> 3);
+    split = w / nwg;
+    flat_tile = w - split * nwg;
+  }
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nt = (kend - kbeg) / TK;
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
     // XCD-aware bijective map (an XCD owns a contiguous range of tiles; with gridDim.x a multiple of 8
     // a block stays on one XCD's range for all its tiles)
     const int xcd = it & 7, q8 = nwg >> 3, rem = nwg & 7;
-    const int vt = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (it >> 3);
+    const int vt = flat_tile >= 0 ? it : (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (it >> 3);
     // inside an XCD's range walk groups of kGroupM tile rows column by column: the group's A panels
     // and the current B panel stay in that XCD's L2
     constexpr int kGroupM = 8;
@@ -193,10 +207,11 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (size_t)(src_off[which][1] + k0)), (lds_ptr_t)(dst + 8192), 16, 0,
                                      0);
   };
-  // K-tile 0 and the first two half-tiles of K-tile 1: what the main loop expects to be in flight
+  // K-tiles 0 and 1, all eight half-tiles (both LDS buffers): issued before the previous tile's output stores, so
+  // that everything the first K-tile and a half needs is OLDER than those stores in the wave's memory queue
   auto issue_prologue = [&]() {
     issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0);
-    if (nt > 1) { issue(0, 1); issue(2, 1); }
+    if (nt > 1) { issue(0, 1); issue(2, 1); issue(3, 1); issue(1, 1); }
   };
 
   f32x4 acc[8][4];
@@ -229,18 +244,48 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
   do {                                                                                         \
     if ((TILE) < nt) { issue(WHICH, TILE); WAIT_VM(6); } else { WAIT_VM(0); }                  \
   } while (0)
+  // The memory counter retires in issue order (loads, LDS-DMA and stores alike), so `vmcnt(N)` means "all but the N
+  // youngest are done". The previous tile's s_out output stores sit between this tile's prologue (issued before that
+  // tile's epilogue) and the DMA issued inside this tile's first K-tiles: a wait that only needs something OLDER than the stores adds
+  // them to its count and leaves them in flight (they drain under the first K-tile and a half instead of in front of
+  // the main loop).
+#define WAIT_6S()                                                                              \
+  do {                                                                                         \
+    if (s_out == 0) WAIT_VM(6); else if (s_out == 16) WAIT_VM(22); else WAIT_VM(38);           \
+  } while (0)
+#define WAIT_8S()                                                                              \
+  do {                                                                                         \
+    if (s_out == 0) WAIT_VM(8); else if (s_out == 16) WAIT_VM(24); else WAIT_VM(40);           \
+  } while (0)
+#define ISSUE_OR_DRAIN_S(WHICH, TILE)                                                          \
+  do {                                                                                         \
+    if ((TILE) < nt) { issue(WHICH, TILE); WAIT_6S(); } else { WAIT_VM(0); }                   \
+  } while (0)
 
-  int it = blockIdx.x;
+  int it = flat_tile >= 0 ? flat_tile : (int)blockIdx.x;
   const bool stamp = g.stamps != nullptr && tid == 0;
-  if (stamp) g.stamps[blockIdx.x * 4 + 0] = wall_clock64();
+  // Workgroups of equal work that start together also store together (measurement hook: the first round of
+  // workgroups, one per CU, starts in four groups g.stagger ticks apart; no effect measured)
+  if (g.stagger > 0) {
+    const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+    const int grp = (lin >> 3) & 3;
+    if (lin < kCusStagger && grp) {
+      const long long until = wall_clock64() + (long long)grp * g.stagger;
+      while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  int s_out = 0;     // output stores of the previous tile that may still be in flight (per wave: 0, 16 or 32)
   if (it < nwg) { setup_tile(it); issue_prologue(); }
-  for (; it < nwg; it += gridDim.x) {
+  const int it_step = flat_tile >= 0 ? nwg : (int)gridDim.x;     // a split-K workgroup owns one tile
+  for (; it < nwg; it += it_step) {
     const int cm0 = m0, cn0 = n0;
-    // everything outstanding (this tile's prologue, the previous tile's stores) has landed
-    WAIT_VM(0);
+    const int next = it + it_step;
+    if (stamp) g.stamps[(split * nwg + it) * 4 + 0] = wall_clock64();
+    // K-tile 0 has landed; K-tile 1 and the previous tile's stores may still be in flight
+    if (nt > 1) WAIT_8S(); else WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // the two row groups run one barrier apart
-    if (stamp && it == (int)blockIdx.x) g.stamps[blockIdx.x * 4 + 1] = wall_clock64();
+    if (stamp) g.stamps[(split * nwg + it) * 4 + 1] = wall_clock64();
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -252,7 +297,14 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
       LOAD_B(b0, 0);
       __builtin_amdgcn_sched_barrier(0);
       LOAD_A(0);
-      ISSUE_OR_DRAIN(3, t + 1);
+      if (t == 0) {
+        // B1 of K-tile 1 came with the prologue, and the wait at the top covered this K-tile
+      } else if (t == 1) {
+        ISSUE_OR_DRAIN_S(3, t + 1);
+        s_out = 0;                      // the next wait (A0 of K-tile 2, younger than the stores) retires them
+      } else {
+        ISSUE_OR_DRAIN(3, t + 1);
+      }
       __builtin_amdgcn_s_barrier();
       WAIT_LGKM0();
       __builtin_amdgcn_sched_barrier(0);
@@ -261,7 +313,11 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
       __builtin_amdgcn_s_barrier();
       // phase 1: quadrant (A0, B1)
       LOAD_B(b1, 1);
-      ISSUE_OR_DRAIN(1, t + 1);
+      if (t == 0) {
+        if (nt > 1) WAIT_6S(); else WAIT_VM(0);     // A1 of K-tile 1 came with the prologue
+      } else {
+        ISSUE_OR_DRAIN(1, t + 1);
+      }
       __builtin_amdgcn_s_barrier();
       WAIT_LGKM0();
       __builtin_amdgcn_sched_barrier(0);
@@ -270,7 +326,7 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
       __builtin_amdgcn_s_barrier();
       // phase 2: quadrant (A1, B1)
       LOAD_A(1);
-      ISSUE_OR_DRAIN(0, t + 2);
+      if (t == 0) ISSUE_OR_DRAIN_S(0, t + 2); else ISSUE_OR_DRAIN(0, t + 2);
       __builtin_amdgcn_s_barrier();
       WAIT_LGKM0();
       __builtin_amdgcn_sched_barrier(0);
@@ -278,20 +334,20 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       // phase 3: quadrant (A1, B0), fragments already in registers
-      ISSUE_OR_DRAIN(2, t + 2);
+      if (t == 0) ISSUE_OR_DRAIN_S(2, t + 2); else ISSUE_OR_DRAIN(2, t + 2);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       MFMA_Q(1, 0, b0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
     }
+    s_out = 0;
     if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the other group's last barrier
     WAIT_VM(0);
     __syncthreads();                             // every wave is done reading the operand buffers
-    if (stamp && it == (int)blockIdx.x) g.stamps[blockIdx.x * 4 + 2] = wall_clock64();
+    if (stamp) g.stamps[(split * nwg + it) * 4 + 2] = wall_clock64();
 
-    // bias is added here, with ordinary loads that are waited for before the next tile's DMA is
-    // issued: nothing in the rest of the epilogue then has to drain that DMA
+    // bias is added here, with ordinary loads that are waited for before the next tile's DMA is issued
     if (g.splits == 1 && g.bias) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -312,7 +368,6 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
     WAIT_VM(0);
     __builtin_amdgcn_sched_barrier(0);
 
-    const int next = it + gridDim.x;
     if (next < nwg) { setup_tile(next); issue_prologue(); }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -336,27 +391,31 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
       continue;
     }
 
-    // ---- epilogue: activation in fp32; a wave stages one 64 x 32 quadrant at a time in its 4 KiB of the
-    // spare LDS and writes 64-byte row segments with 16-byte stores. The activation and the accumulate
-    // input are compile-time choices of the body: tested per element they cost a branch (and the
-    // instruction fetch of the skipped code) 128 times per lane.
+    // ---- epilogue: activation in fp32, then each lane turns its two 8-byte pieces of a 16-row slice (4 consecutive
+    // columns of the two 16-column groups) into ONE 16-byte piece by a row swap with its neighbour (v_permlane16_swap:
+    // even 16-lane rows keep the first group and receive the neighbour's first group, odd rows the second), so that a
+    // store instruction writes 16 rows of 64 contiguous bytes straight from registers: no staging through LDS, no LDS
+    // round trip between the conversion and the store (the staged form spent 3.6 us per tile issuing its 16 stores,
+    // each behind its own ds_read and wait). The activation and the accumulate input are compile-time choices of the
+    // body: tested per element they cost a branch (and the instruction fetch of the skipped code) 128 times per lane.
     // The epilogue's indices are re-derived from values the compiler cannot trace back past this point: otherwise
     // it hoists the epilogue's address arithmetic above the main loop, where the extra live registers spill.
     int cm0e = cm0, cn0e = cn0, lane_e = lane;
     asm volatile("" : "+s"(cm0e), "+s"(cn0e), "+v"(lane_e));
     const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
-    char* blk = smem + kLds256 + wid * 4096;
+    const int col_e = (fq_e & 1) * 16 + (fq_e >> 1) * 8;     // first of the lane's 8 columns inside the wave's 32
     auto epilogue = [&](auto act_c, auto cin_c) {
       constexpr int ACT = decltype(act_c)::value;     // 0 none, 1 relu, 2 gelu, 3 gelu + its derivative into C2
       constexpr int CIN = decltype(cin_c)::value;     // 0 none, 1 add Cin, 2 multiply by Cin
       // The combine input comes in by LDS-DMA, all 16 KiB of the wave's four quadrants at once, into the operand
       // buffers the main loop no longer needs: one exposed fetch latency instead of one per quadrant, and no
       // registers (holding even one quadrant ahead in registers spills). Only when no next tile's prologue
-      // owns those buffers, i.e. one workgroup per tile; the persistent grid keeps the per-store fetch.
-      // Full tiles only (no clamping of edge addresses): a wave-uniform base per 16-row slice plus ONE per-lane_e
+      // owns those buffers, i.e. one workgroup per tile; the persistent grid fetches a quadrant's four pieces with
+      // ordinary loads before that quadrant's first store.
+      // Full tiles only (no clamping of edge addresses): a wave-uniform base per 16-row slice plus ONE per-lane
       // 32-bit offset, so the 16 fetches cost no address registers either.
-      const bool cin_dma = CIN != 0 && next >= nwg && (int)gridDim.x >= nwg && cm0e + TM <= g.M && cn0e + TN <= g.N;
-      char* cbuf = smem + wid * 16384;
+      const bool cin_dma = CIN != 0 && next >= nwg && it_step >= nwg && cm0e + TM <= g.M && cn0e + TN <= g.N;
+      const char* cbuf = smem + wid * 16384 + fr_e * 64 + (col_e >> 3) * 16;
       if (CIN != 0 && cin_dma) {
         __syncthreads();          // every wave has read its last operand fragments
         const int wu = __builtin_amdgcn_readfirstlane(wid);
@@ -370,23 +429,34 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(sbase + lane_off),
                                              (lds_ptr_t)(smem + wu * 16384 + q * 4096 + v * 1024), 16, 0, 0);
           }
+        WAIT_VM(0);
       }
 #pragma unroll
       for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
         for (int qj = 0; qj < 2; ++qj) {
-          u32x2 side[ACT == 3 ? 8 : 1];
+          const int n = cn0e + qj * 128 + wc * 32 + col_e;
+          const int mq = cm0e + qi * 128 + wr * 64 + fr_e;
+          const long long off0 = (long long)mq * g.ldc + n;
+          u32x4 ci[4];
+          if (CIN != 0 && !cin_dma) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+              ci[i] = u32x4{0u, 0u, 0u, 0u};
+              if (mq + i * 16 < g.M && n < g.N) ci[i] = *reinterpret_cast<const u32x4*>(g.Cin + off0 + (long long)i * 16 * g.ldc);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            u32x4 val, der;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               f32x4 v = acc[qi * 4 + i][qj * 2 + j];
               if (ACT == 3) {
                 const f32x4 lo = gelu_pair256(f32x2_256{v[0], v[1]}), hi = gelu_pair256(f32x2_256{v[2], v[3]});
                 v = f32x4{lo[0], lo[1], hi[0], hi[1]};
-                const f32x4 d = {lo[2], lo[3], hi[2], hi[3]};
-                side[i * 2 + j][0] = pack_bf16x2(d[0], d[1]);
-                side[i * 2 + j][1] = pack_bf16x2(d[2], d[3]);
+                der[j * 2 + 0] = pack_bf16x2(lo[2], lo[3]);
+                der[j * 2 + 1] = pack_bf16x2(hi[2], hi[3]);
               } else if (ACT == 2) {
                 const f32x4 lo = gelu_pair256(f32x2_256{v[0], v[1]}), hi = gelu_pair256(f32x2_256{v[2], v[3]});
                 v = f32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -394,49 +464,40 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
               }
-              u32x2 o;
-              o[0] = pack_bf16x2(v[0], v[1]);
-              o[1] = pack_bf16x2(v[2], v[3]);
-              *reinterpret_cast<u32x2*>(blk + (i * 16 + fr_e) * 64 + j * 32 + fq_e * 8) = o;
+              val[j * 2 + 0] = pack_bf16x2(v[0], v[1]);
+              val[j * 2 + 1] = pack_bf16x2(v[2], v[3]);
             }
-          // the staging block is private to the wave: LDS operations of one wave execute in order
-          if (CIN != 0 && cin_dma && qi == 0 && qj == 0) WAIT_VM(0);
+            // {group 0 | group 1} per lane -> 8 consecutive columns per lane
 #pragma unroll
-          for (int pass = 0; pass < (ACT == 3 ? 2 : 1); ++pass) {
-            if (pass == 1) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                  *reinterpret_cast<u32x2*>(blk + (i * 16 + fr_e) * 64 + j * 32 + fq_e * 8) = side[ACT == 3 ? i * 2 + j : 0];
-            }
-            unsigned short* dst = pass == 0 ? g.C : g.C2;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const int idx = v * 64 + lane_e;
-              const int row = idx >> 2, c16 = idx & 3;
-              const int m = cm0e + qi * 128 + wr * 64 + row;
-              const int n = cn0e + qj * 128 + wc * 32 + c16 * 8;
-              u32x4 val = *reinterpret_cast<const u32x4*>(blk + row * 64 + c16 * 16);
-              if (m < g.M && n < g.N) {
-                if (CIN != 0) {
-                  // out = bf16(bf16(acc) (+|*) C_in): the rounding of an unfused GEMM followed by an elementwise kernel
-                  const u32x4 ci = cin_dma ? *reinterpret_cast<const u32x4*>(cbuf + (qi * 2 + qj) * 4096 + idx * 16)
-                                           : *reinterpret_cast<const u32x4*>(g.Cin + (long long)m * g.ldc + n);
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) {
-                    const float a0 = __uint_as_float(val[e] << 16), a1 = __uint_as_float(val[e] & 0xffff0000u);
-                    const float c0 = __uint_as_float(ci[e] << 16), c1 = __uint_as_float(ci[e] & 0xffff0000u);
-                    const float lo = CIN == 1 ? a0 + c0 : a0 * c0;
-                    const float hi = CIN == 1 ? a1 + c1 : a1 * c1;
-                    val[e] = pack_bf16x2(lo, hi);
-                  }
-                }
-                *reinterpret_cast<u32x4*>(dst + (long long)m * g.ldc + n) = val;
+            for (int h = 0; h < 2; ++h) {
+              const u32x2 sw = __builtin_bit_cast(u32x2, __builtin_amdgcn_permlane16_swap(val[h], val[2 + h], false, false));
+              const unsigned s0 = sw[0], s1 = sw[1];
+              val[h] = s0; val[2 + h] = s1;
+              if (ACT == 3) {
+                const u32x2 sd = __builtin_bit_cast(u32x2, __builtin_amdgcn_permlane16_swap(der[h], der[2 + h], false, false));
+                const unsigned d0 = sd[0], d1 = sd[1];
+                der[h] = d0; der[2 + h] = d1;
               }
             }
+            const bool inside = mq + i * 16 < g.M && n < g.N && g.stagger != -1;
+            if (CIN != 0) {
+              // out = bf16(bf16(acc) (+|*) C_in): the rounding of an unfused GEMM followed by an elementwise kernel
+              const u32x4 cv = cin_dma ? *reinterpret_cast<const u32x4*>(cbuf + (qi * 2 + qj) * 4096 + i * 1024) : ci[i];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float a0 = __uint_as_float(val[e] << 16), a1 = __uint_as_float(val[e] & 0xffff0000u);
+                const float c0 = __uint_as_float(cv[e] << 16), c1 = __uint_as_float(cv[e] & 0xffff0000u);
+                const float lo = CIN == 1 ? a0 + c0 : a0 * c0;
+                const float hi = CIN == 1 ? a1 + c1 : a1 * c1;
+                val[e] = pack_bf16x2(lo, hi);
+              }
+            }
+            if (inside) {
+              *reinterpret_cast<u32x4*>(g.C + off0 + (long long)i * 16 * g.ldc) = val;
+              if (ACT == 3) *reinterpret_cast<u32x4*>(g.C2 + off0 + (long long)i * 16 * g.ldc) = der;
+            }
           }
-      }
+        }
     };
     using std::integral_constant;
     if (g.Cin) {
@@ -446,20 +507,36 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
     else if (g.act == 1) epilogue(integral_constant<int, 1>{}, integral_constant<int, 0>{});
     else if (g.act == 2) epilogue(integral_constant<int, 2>{}, integral_constant<int, 0>{});
     else epilogue(integral_constant<int, 3>{}, integral_constant<int, 0>{});
-    if (stamp && it == (int)blockIdx.x) {
-      g.stamps[blockIdx.x * 4 + 2] = wall_clock64() - g.stamps[blockIdx.x * 4 + 2];   // issue time of the epilogue
-      WAIT_VM(0);
-      g.stamps[blockIdx.x * 4 + 3] = wall_clock64();
+    // a full tile issued exactly 16 (32 with the derivative output) stores per wave after the next tile's prologue:
+    // the counted waits of that tile's first K-tiles let them fly. An edge tile skips stores lane by lane and wave
+    // by wave, so its count is unknown: drain.
+    if (next < nwg) {
+      if (cm0 + TM <= g.M && cn0 + TN <= g.N && g.stagger != -1) {
+        s_out = (!g.Cin && g.act == 3) ? 32 : 16;
+      } else {
+        WAIT_VM(0);
+        s_out = 0;
+      }
     }
+    if (stamp) g.stamps[(split * nwg + it) * 4 + 3] = wall_clock64();
   }
 }
 
 }  // namespace
 
 static long long* g_stamps256 = nullptr;
-// diagnostic: device buffer of 4 * gridDim.x 64-bit stamps filled by the next launches (null = off)
+// diagnostic: device buffer of 4 * tiles * splits 64-bit stamps filled by the next launches (null = off)
 DTF_API void dtf_gemm256_set_stamps(void* p) { g_stamps256 = (long long*)p; }
-static int g_persist256 = 0;   // measured neutral for NT/NN and worse with split-K: the output burst, not the prologue, bounds short-K shapes
+static int g_stagger256 = 0;
+// measurement hooks: ticks of 10 ns between the four start groups of the first round of workgroups; -1 = the kernel
+// without its output stores (what the stores cost: 17 % of a 65536 x 3072 x 768 product)
+DTF_API void dtf_gemm256_set_stagger(int ticks) { g_stagger256 = ticks; }
+// persistent grid for launches without split-K (slabs: one workgroup per tile and split); DTF_GEMM256_PERSISTENT=0
+// restores one workgroup per tile for A/B runs
+static int g_persist256 = [] {
+  const char* e = getenv("DTF_GEMM256_PERSISTENT");
+  return e && e[0] == '0' ? 0 : 1;
+}();
 constexpr int kCus256 = 256;
 
 // 1: persistent grid (one workgroup per CU walks several tiles), 0: one workgroup per tile (measurement hook)
@@ -513,11 +590,12 @@ DTF_API int dtf_gemm256_ex(int layout, const void* A, const void* B, void* C, co
   g.W = (float*)workspace; g.k_per_split = kps; g.splits = splits; g.Cin = (const unsigned short*)cin;
   g.cin_mode = cin ? cin_mode : 0; g.C2 = (unsigned short*)c2;
   g.stamps = g_stamps256;
+  g.stagger = g_stagger256;
   // persistent: one workgroup per CU (the kernel takes the whole LDS), each walking its share of tiles
   const int nwg = g.tiles_m * g.tiles_n;
-  int gx = g_persist256 ? (kCus256 / splits > 8 ? kCus256 / splits / 8 * 8 : 8) : nwg;
+  int gx = g_persist256 && splits == 1 ? kCus256 : nwg;
   if (gx > nwg) gx = nwg;
-  const dim3 grid(gx, splits);
+  const dim3 grid(splits > 1 ? nwg * splits : gx, 1);
   switch (layout) {
     case 0: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid, dim3(kT256), kLdsAll, stream, g); break;
     case 1: hipLaunchKernelGGL((gemm256_kernel<0, 1>), grid, dim3(kT256), kLdsAll, stream, g); break;

@@ -778,6 +778,52 @@ def test_gemm256_deep_pipeline_matches_reference(shape, act):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(16640, 1280, 256), (20008, 1032, 192), (70000, 264, 128), (70000, 256, 64),
+                                   (33000, 768, 768)])
+def test_gemm256_several_tiles_per_workgroup(shape):
+    """More output tiles than CUs: a workgroup walks several tiles, the next tile's operands are requested before the
+    current tile's stores and those stores stay in flight under the next main loop (full tiles) or are drained (edge
+    tiles). Every epilogue, both operand orientations, even / odd / one / two K-tiles; repeated launches must agree
+    bit for bit (a wait that counts wrongly shows up as flicker)."""
+    from distributed_tensorflow_amd.ops import gemm
+    M, N, K = shape
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    b = torch.randn(N, K, device=DEV).bfloat16()
+    bt = b.t().contiguous()
+    bias = torch.randn(N, device=DEV)
+    cin = torch.randn(M, N, device=DEV).bfloat16()
+    prod = a.float() @ b.float().t()
+    scale = max(1.0, float(prod.abs().max()))
+
+    def close(out, ref):
+        assert torch.allclose(out.float() / scale, ref / scale, atol=1e-2, rtol=2e-2), float((out.float() - ref).abs().max())
+
+    out = gemm.gemm256_nt(a, b, bias, "relu")
+    close(out, torch.relu(prod + bias))
+    for _ in range(2):
+        assert torch.equal(out, gemm.gemm256_nt(a, b, bias, "relu"))
+    out = gemm.gemm256(gemm.NN, a, bt, M, N, K)
+    close(out, prod)
+    assert torch.equal(out, gemm.gemm256(gemm.NN, a, bt, M, N, K))
+    out = gemm.gemm256(gemm.NN, a, bt, M, N, K, add=cin)
+    close(out, prod.bfloat16().float() + cin.float())
+    assert torch.equal(out, gemm.gemm256(gemm.NN, a, bt, M, N, K, add=cin))
+    out = gemm.gemm256(gemm.NN, a, bt, M, N, K, mul=cin)
+    close(out, prod.bfloat16().float() * cin.float())
+    assert torch.equal(out, gemm.gemm256(gemm.NN, a, bt, M, N, K, mul=cin))
+    der = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    out = gemm.gemm256(gemm.NT, a, b, M, N, K, bias, "gelu", grad_out=der)
+    pre = (prod + bias).requires_grad_(True)
+    ref = torch.nn.functional.gelu(pre)
+    close(out, ref.detach())
+    (dref,) = torch.autograd.grad(ref.sum(), pre)
+    assert torch.allclose(der.float(), dref, atol=2e-2, rtol=2e-2)
+    der2 = torch.empty_like(der)
+    assert torch.equal(out, gemm.gemm256(gemm.NT, a, b, M, N, K, bias, "gelu", grad_out=der2)) and torch.equal(der, der2)
+
+
+@pytest.mark.gpu
 def test_gemm256_operand_orientation():
     from distributed_tensorflow_amd.ops import gemm
     M = N = K = 256
