@@ -45,9 +45,10 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=None,
-                    help="per-GPU batch (weak scaling: fixed per GPU); default 1024 images (ResNet-50: 4 %% above 512\n"
-                         "on one MI355X, the per-layer reduction kernels are amortised over more work) / 128 sequences (10 %% above 64:\n"
-                         "the 768-wide products then fill whole rounds of 256 x 256 tiles)")
+                    help="per-GPU batch (weak scaling: fixed per GPU); default 2048 images (ResNet-50: 1.5-2 %% above 1024 and\n"
+                         "6 %% above 512 on one MI355X -- the per-layer reduction kernels and ~550 launch boundaries are amortised\n"
+                         "over more work; 86 GiB of the 288 GB) / 128 sequences (10 %% above 64: the 768-wide products then fill\n"
+                         "whole rounds of 256 x 256 tiles)")
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--bucket-mb", type=int, default=None, help="gradient bucket size (default 48 MiB)")
@@ -108,7 +109,7 @@ def main() -> int:
     gdt = torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32
     if a.model == "resnet50":
         strategy = a.strategy or "keras"
-        batch = a.batch or int(os.environ.get("DTF_BENCH_BATCH", "1024"))
+        batch = a.batch or int(os.environ.get("DTF_BENCH_BATCH", "2048"))
 
         def make(c, s_):
             return bench_lib.make_resnet50_strategy(c, bucket_mb=bucket_mb, grad_dtype=gdt, strategy=s_)

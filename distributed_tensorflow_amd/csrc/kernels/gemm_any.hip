@@ -144,7 +144,10 @@ template <typename TA, typename TB, typename TC, int GM = 0>
 __global__ __launch_bounds__(256) void gemm_any_kernel(AnyArgs g) {
   __shared__ float As[TK * kPitch];
   __shared__ float Bs[TK * kPitch];
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  // tiles folded into grid.x (column tiles fastest): grid.y would cap the rows at 65535 tiles
+  const int tiles_n = (g.N + TN - 1) / TN;
+  const int tile_m = blockIdx.x / tiles_n;
+  const int m0 = tile_m * TM, n0 = (blockIdx.x - tile_m * tiles_n) * TN;
   const int split = blockIdx.z;
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
@@ -302,8 +305,9 @@ static int gemm_any_launch(int gm, const ConvGather* cg, const void* A, int a_dt
   g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K; g.k_per_split = kps; g.splits = splits; g.bias_dtype = bias_dtype; g.act = act;
   if (cg) g.cg = *cg; else g.cg = ConvGather{};
-  const dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM, splits);
-  if (grid.y > 65535u || grid.z > 65535u) return -2;
+  const long long tiles = (long long)((N + TN - 1) / TN) * ((M + TM - 1) / TM);
+  if (tiles > 0x7fffffffLL || splits > 65535) return -2;
+  const dim3 grid((unsigned)tiles, 1, splits);
   if (gm != 0) {
 #define LG(GM_)                                                                       \
   do {                                                                                \

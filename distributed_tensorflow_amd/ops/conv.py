@@ -395,13 +395,16 @@ class _FirstConvFn(torch.autograd.Function):
         return gx, gw, None, None, None, gb, None, None
 
 
-def _gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+def _gemm_ok(x: torch.Tensor, w: torch.Tensor, stride: int = 1) -> bool:
+    pixels = x.shape[0] * x.shape[2] * x.shape[3]
+    # output pixels, bounded from above for any padding below the kernel size
+    out_pixels = x.shape[0] * ((x.shape[2] + w.shape[2] - 2) // stride + 1) * ((x.shape[3] + w.shape[3] - 2) // stride + 1)
     return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.shape[1] % 8 == 0
             and w.shape[0] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)
             and w.is_contiguous(memory_format=torch.channels_last)
-            and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)
+            and pixels < (1 << 24)
             # operands are addressed with 32-bit byte offsets (buffer descriptors): below 2^31 elements each
-            and x.shape[0] * x.shape[2] * x.shape[3] * max(x.shape[1], w.shape[0]) < (1 << 31))
+            and pixels * x.shape[1] < (1 << 31) and out_pixels * w.shape[0] < (1 << 31))
 
 
 _bn_stats = os.environ.get("DTF_CONV_BN_STATS", "1") != "0"
@@ -436,7 +439,7 @@ def _norm_request(x):
 
 
 def _own_path(x, w, stride) -> bool:
-    return (stride in (1, 2) and _gemm_ok(x, w)
+    return (stride in (1, 2) and _gemm_ok(x, w, stride)
             and (stride == 1 or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)))
 
 

@@ -1616,3 +1616,15 @@ def test_fp32_convolution_has_no_library_route():
         torch.testing.assert_close(y.float(), yr.detach(), **tol)
         torch.testing.assert_close(x1.grad.float(), xr.grad, **tol)
         torch.testing.assert_close(w1.grad.float(), wr.grad, **(tol if dtype == torch.float32 else dict(rtol=5e-2, atol=0.15)))
+
+
+def test_general_convolution_with_more_than_65535_row_tiles():
+    """The general (fallback) convolution folds its row tiles into grid.x: 4.46 million output pixels are 69,696 tiles of
+    64 rows, which a grid.y could not hold (a 1536-image ResNet-50 stem reached this and failed to launch)."""
+    from distributed_tensorflow_amd.ops import conv
+    torch.manual_seed(2)
+    x = torch.randn(36, 3, 352, 352, device=DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(8, 3, 3, 3, device=DEV) * 0.2).contiguous(memory_format=torch.channels_last)
+    y = conv.conv2d(x, w, 1, 1)
+    ref = torch.nn.functional.conv2d(x, w, None, 1, 1)
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
