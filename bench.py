@@ -47,8 +47,8 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=None,
                     help="per-GPU batch (weak scaling: fixed per GPU); default 2048 images (ResNet-50: 1.5-2 %% above 1024 and\n"
                          "6 %% above 512 on one MI355X -- the per-layer reduction kernels and ~550 launch boundaries are amortised\n"
-                         "over more work; 86 GiB of the 288 GB) / 128 sequences (10 %% above 64: the 768-wide products then fill\n"
-                         "whole rounds of 256 x 256 tiles)")
+                         "over more work; 86 GiB of the 288 GB) / 384 sequences (BERT: 4-5 %% above 128, 18 %% above 64 -- every\n"
+                         "workgroup of the persistent 256 x 256 GEMM then walks 9 or more output tiles; 60 GiB)")
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--bucket-mb", type=int, default=None, help="gradient bucket size (default 48 MiB)")
@@ -120,7 +120,7 @@ def main() -> int:
     else:
         from distributed_tensorflow_amd.models.bert import synthetic_mlm_batch
         strategy = a.strategy or "custom:direct"
-        batch = a.batch or 128
+        batch = a.batch or 384
         size = "base" if a.model == "bert" else "tiny"
         seq = a.seq_len if size == "base" else min(a.seq_len, 64)
 
