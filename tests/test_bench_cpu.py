@@ -141,3 +141,14 @@ def test_collective_harness_two_ranks_gloo():
     names = {r["backend"] for r in d["results"]}
     assert {"rccl", "custom:direct", "custom:ring", "custom:multiring", "custom:tree", "custom:oneshot", "rs+ag"} <= names
     assert all(r["correct"] and r["us"] > 0 for r in d["results"])
+
+
+def test_wide_and_deep_rank_tool_runs_on_cpu():
+    """tools/bench_widedeep_ranks.py (config 5 with all shards as processes of one device): plumbing mode, 2 ranks."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_widedeep_ranks.py"), "--device", "cpu", "--ranks", "2",
+           "--state-gb", "0.01", "--batch", "64", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["ranks"] == 2 and r["dense_replicas_identical"] and r["rows_pulled_per_rank"] == 3 * 64 * 26
+    assert r["loss_first_last"][1] < r["loss_first_last"][0]

@@ -30,8 +30,11 @@ def worker(rank, world, port, q, a):
         from distributed_tensorflow_amd.engine.replica import TrainConfig
         from distributed_tensorflow_amd.models import wide_deep as wd
         from distributed_tensorflow_amd.parallel.ps import SyncPSStrategy
-        dev = torch.device("cuda", 0)
-        torch.cuda.set_device(dev)
+        dev = torch.device("cuda", 0) if a.device == "gpu" else torch.device("cpu")
+        if dev.type == "cuda":
+            torch.cuda.set_device(dev)
+        else:
+            torch.set_num_threads(1)
         comm = Comm.init(rank, world, dev, "127.0.0.1", 0, timeout_s=600, backend="gloo", port_cell=port)
         emb_dim, wide_dim = 128, 4
         # state per row: table + Adagrad accumulator, both tables, fp32
@@ -39,18 +42,20 @@ def worker(rank, world, port, q, a):
         rows -= rows % world
         torch.manual_seed(0)
         model = wd.WideDeep(comm, rows, emb_dim=emb_dim, wide_dim=wide_dim)
-        cfg = TrainConfig(loss=wd.bce_loss, loss_reduction="mean", param_dtype=torch.bfloat16)
+        cfg = TrainConfig(loss=wd.bce_loss, loss_reduction="mean",
+                          param_dtype=torch.bfloat16 if dev.type == "cuda" else torch.float32)
         st = SyncPSStrategy(model, comm, cfg, optimizer=Adam(learning_rate=1e-3))
         x, y = wd.synthetic_batch(a.batch, rows, model.n_sparse, model.n_dense, dev, seed=rank)
         losses = []
         for _ in range(a.warmup):
             losses.append(float(st.train_step(x, y)))
         comm.barrier()
-        torch.cuda.synchronize(dev)
+        sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
+        sync()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             losses.append(float(st.train_step(x, y)))
-        torch.cuda.synchronize(dev)
+        sync()
         comm.barrier()
         dt = (time.perf_counter() - t0) / a.steps
         st.finalize()
@@ -58,7 +63,7 @@ def worker(rank, world, port, q, a):
         q.put((rank, {"ms_per_step": dt * 1e3, "losses": losses,
                       "shard_state_gb": sum(m.nbytes() for m in model.sparse_modules()) / (1 << 30),
                       "rows": rows, "rows_pulled": model.deep_emb.rows_pulled,
-                      "allocated_gb": torch.cuda.max_memory_allocated(dev) / (1 << 30),
+                      "allocated_gb": torch.cuda.max_memory_allocated(dev) / (1 << 30) if dev.type == "cuda" else 0.0,
                       "dense_checksum": float(dense.double().sum()), "dense_absmax": float(dense.abs().max())}))
         comm.barrier()
         comm.shutdown()
@@ -73,6 +78,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="examples per rank and step")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--device", default="gpu", choices=["gpu", "cpu"], help="cpu: plumbing check of this tool")
     a = ap.parse_args()
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), ctx.Value("i", 0)
