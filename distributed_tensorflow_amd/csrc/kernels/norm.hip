@@ -208,15 +208,18 @@ __device__ __forceinline__ u16x8 ldraw(const unsigned short* p) {
   return NT ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p)) : *reinterpret_cast<const u16x8*>(p);
 }
 
-// y = act(x*scale + shift (+ res))
-template <int R, bool NT>
+// y = act(x*scale + shift (+ res)). RN: the residual is itself a batch norm whose apply pass never ran (the norm of a
+// down-sampling branch): res holds that norm's INPUT and rscale / rshift its coefficients, so the branch's normalised
+// tensor is neither written nor read back (4 bytes per element of the widest activations of a stage).
+template <int R, bool NT, bool RN = false>
 __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(const unsigned short* __restrict__ x,
                                                               const unsigned short* __restrict__ res,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               unsigned short* __restrict__ y,
                                                               unsigned char* __restrict__ mask, long long M, int C,
-                                                              int relu) {
+                                                              int relu, const float* __restrict__ rscale = nullptr,
+                                                              const float* __restrict__ rshift = nullptr) {
   const int c8 = C >> 3;
   const long long n8 = M * c8;
   const bool fixed = (kBlock % c8) == 0;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(const unsigned sho
         if (res) rr[k] = ldraw<NT>(res + i * 8);
       }
     }
-    float a[8], b[8];
+    float a[8], b[8], ra[RN ? 8 : 1];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       const long long i = i0 + k * kBlock;
@@ -239,16 +242,23 @@ __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(const unsigned sho
       if (k == 0 || !fixed) {
         const int c = (int)(i % c8) << 3;
         ld8f(scale + c, a); ld8f(shift + c, b);
+        if constexpr (RN) {
+          // the two shifts add up front: one vector less to keep
+          float rb[8];
+          ld8f(rscale + c, ra); ld8f(rshift + c, rb);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) b[e] += rb[e];
+        }
       }
       float v[8];
       cvt8(xr[k], v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], a[e], b[e]);
-      if (res) {
+      if (RN || res) {
         float r[8];
         cvt8(rr[k], r);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r[e];
+        for (int e = 0; e < 8; ++e) v[e] = RN ? fmaf(r[e], ra[RN ? e : 0], v[e]) : v[e] + r[e];
       }
       if (mask) {      // sign bits of the pre-activation: the backward pass reads 1 byte instead of 16
         unsigned mb = 0;
@@ -339,14 +349,20 @@ DTF_API int dtf_set_bn_apply_rows(int r, int nt) {
 }
 
 static void launch_apply_fwd(const void* x, const void* res, const float* scale, const float* shift, void* y,
-                             void* mask, long long M, int C, int relu, hipStream_t stream) {
-#define AF(R, NT)                                                                                                       \
-  hipLaunchKernelGGL((bn_apply_fwd_kernel<R, NT>), dim3(grid_stream(M * (C / 8), kBlock * R)), dim3(kBlock), 0, stream, \
+                             void* mask, long long M, int C, int relu, hipStream_t stream,
+                             const float* rscale = nullptr, const float* rshift = nullptr) {
+#define AFN(R, NT, RN)                                                                                                  \
+  hipLaunchKernelGGL((bn_apply_fwd_kernel<R, NT, RN>), dim3(grid_stream(M * (C / 8), kBlock * R)), dim3(kBlock), 0, stream, \
                      (const unsigned short*)x, (const unsigned short*)res, scale, shift, (unsigned short*)y,       \
-                     (unsigned char*)mask, M, C, relu)
+                     (unsigned char*)mask, M, C, relu, rscale, rshift)
+#define AF(R, NT)                                                                                                       \
+  do {                                                                                                                  \
+    if (rscale && res) AFN(R, NT, true); else AFN(R, NT, false);                                                        \
+  } while (0)
   if (g_apply_nt) { if (g_apply_rows == 4) AF(4, true); else if (g_apply_rows == 2) AF(2, true); else AF(1, true); }
   else { if (g_apply_rows == 4) AF(4, false); else if (g_apply_rows == 2) AF(2, false); else AF(1, false); }
 #undef AF
+#undef AFN
 }
 
 static void launch_apply_bwd(const void* x, const void* dy, const void* y, const float* coef, const float* scale,
@@ -535,11 +551,11 @@ constexpr int kFoldAbove = kBnMaxPartials; // the finalize kernels take up to th
 // dtf_bn_fwd_train with the batch statistics already reduced to partial rows by the producer of x: col_stats is
 // fp32 [n_rows][2][C] (sum, sum of squares per channel over disjoint row sets that cover all M rows), so x is read
 // once (by the apply pass) instead of twice. workspace: fp32 [kFoldRows * 2 * C] (used when n_rows > kFoldAbove).
-DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+static int bn_fwd_train_stats_impl(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                                    float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
                                    float* shift, const float* col_stats, int n_rows, float* workspace, void* mask_out,
                                    long long M, int C, float eps, float momentum, int relu, void* counters,
-                                   hipStream_t stream) {
+                                   const float* rscale, const float* rshift, hipStream_t stream) {
   if (M <= 0 || C <= 0) return 0;
   if (C % 8 || !col_stats || n_rows < 1) return -1;
   const float* part = col_stats;
@@ -549,7 +565,7 @@ DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, cons
     f.gamma = gamma; f.beta = beta; f.run_mean = run_mean; f.run_var = run_var; f.mean = mean; f.invstd = invstd;
     f.scale = scale; f.shift = shift; f.eps = eps; f.momentum = momentum; f.M = M; f.C = C;
     launch_reduce_finalize<0>(col_stats, n_rows, workspace, (unsigned*)counters, f, stream);
-    if (y) launch_apply_fwd(x, res, scale, shift, y, mask_out, M, C, relu, stream);
+    if (y) launch_apply_fwd(x, res, scale, shift, y, mask_out, M, C, relu, stream, rscale, rshift);
     return (int)hipGetLastError();
   }
   if (n_rows > kFoldAbove) {
@@ -564,8 +580,29 @@ DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, cons
   // y == null: the consumer of the normalised activation applies scale / shift (/ ReLU) itself while it stages its
   // operand (gemm.hip, operand transform); only the statistics are finished here
   if (y)
-    launch_apply_fwd(x, res, scale, shift, y, mask_out, M, C, relu, stream);
+    launch_apply_fwd(x, res, scale, shift, y, mask_out, M, C, relu, stream, rscale, rshift);
   return (int)hipGetLastError();
+}
+
+DTF_API int dtf_bn_fwd_train_stats(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                                   float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
+                                   float* shift, const float* col_stats, int n_rows, float* workspace, void* mask_out,
+                                   long long M, int C, float eps, float momentum, int relu, void* counters,
+                                   hipStream_t stream) {
+  return bn_fwd_train_stats_impl(x, res, y, gamma, beta, run_mean, run_var, mean, invstd, scale, shift, col_stats, n_rows,
+                                 workspace, mask_out, M, C, eps, momentum, relu, counters, nullptr, nullptr, stream);
+}
+
+// The same with a residual that is the INPUT of another batch norm (rscale, rshift: that norm's fp32 coefficients):
+// y = act(x * scale + shift + res * rscale + rshift)
+DTF_API int dtf_bn_fwd_train_stats_rn(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                                      float* run_mean, float* run_var, float* mean, float* invstd, float* scale,
+                                      float* shift, const float* col_stats, int n_rows, float* workspace,
+                                      void* mask_out, long long M, int C, float eps, float momentum, int relu,
+                                      void* counters, const float* rscale, const float* rshift, hipStream_t stream) {
+  if (!res || !rscale || !rshift || !y) return -1;
+  return bn_fwd_train_stats_impl(x, res, y, gamma, beta, run_mean, run_var, mean, invstd, scale, shift, col_stats, n_rows,
+                                 workspace, mask_out, M, C, eps, momentum, relu, counters, rscale, rshift, stream);
 }
 
 DTF_API int dtf_bn_fwd_apply(const void* x, const void* res, void* y, const float* scale, const float* shift,

@@ -82,6 +82,16 @@ class BNAct(nn.Module):
                 return d
         return self.forward(x, partials=partials)
 
+    def lazy(self, x, partials):
+        """A plain norm (no ReLU) that only feeds the residual input of a norm-add-ReLU: statistics now, the apply
+        inside that norm's kernel (``ops.norm.batch_norm_lazy``) when possible, else the tensor."""
+        if self.training and partials is not None and not self.relu:
+            d = norm_ops.batch_norm_lazy(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                         self.momentum, self.eps, partials)
+            if d is not None:
+                return d
+        return self.forward(x, partials=partials)
+
     def keras_weights(self):
         return [t.detach().float().cpu().numpy() for t in (self.weight, self.bias, self.running_mean, self.running_var)]
 
@@ -92,11 +102,14 @@ class BNAct(nn.Module):
         return 4
 
 
-def _conv_bn(conv: "Conv", bn: "BNAct", x, residual=None):
+def _conv_bn(conv: "Conv", bn: "BNAct", x, residual=None, lazy: bool = False):
     """``bn(conv(x) (+ residual))``; in training the convolution hands the batch norm the partial statistics it
-    gathered while storing its output, so the norm reads that output once instead of twice."""
+    gathered while storing its output, so the norm reads that output once instead of twice. ``lazy``: the result only
+    feeds the residual input of the block's closing norm-add-ReLU (see :meth:`BNAct.lazy`)."""
     if bn.training:
         y, st = conv(x, bn_stats=True)
+        if lazy:
+            return bn.lazy(y, st)
         return bn(y, residual=residual, partials=st)
     return bn(conv(x), residual=residual)
 
@@ -122,7 +135,7 @@ class Bottleneck(nn.Module):
             y, xi, st = conv_ops.conv2d_fork(x, c1.weight, c1.stride, c1.padding, bn_stats=True)
         else:
             (y, xi), st = conv_ops.conv2d_fork(x, c1.weight, c1.stride, c1.padding), None
-        idt = xi if self.down is None else _conv_bn(self.down, self.down_bn, xi)
+        idt = xi if self.down is None else _conv_bn(self.down, self.down_bn, xi, lazy=True)
         # bn1 and bn2 have one consumer each, the next convolution: it normalises while it stages its operand, so
         # their normalised outputs are never written
         y = self.bn1.deferred(y, st)
@@ -155,7 +168,7 @@ class BasicBlock(nn.Module):
         else:
             y, xi = conv_ops.conv2d_fork(x, c1.weight, c1.stride, c1.padding)
             y = self.bn1(y)
-        idt = xi if self.down is None else _conv_bn(self.down, self.down_bn, xi)
+        idt = xi if self.down is None else _conv_bn(self.down, self.down_bn, xi, lazy=True)
         return _conv_bn(self.conv2, self.bn2, y, residual=idt)
 
 

@@ -162,10 +162,11 @@ class _ApplyFn(torch.autograd.Function):
 class _BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, relu, residual, partials=None, request=None,
-                defer=False, out_token=None):
+                defer=False, out_token=None, res_scale=None, res_shift=None):
         """``defer``: finish the statistics only and return an alias of ``x`` (see :class:`DeferredNorm`); needs
         ``partials`` and no residual. ``out_token``: the :class:`ForkToken` of this norm's output (plain norms
-        only)."""
+        only). ``res_scale`` / ``res_shift``: ``residual`` is the alias of a plain norm whose apply pass has not run
+        (:func:`batch_norm_lazy`); the apply kernel normalises it on the fly (needs ``partials``)."""
         ctx.out_token = out_token
         N, C, H, W = x.shape
         M = N * H * W
@@ -191,13 +192,25 @@ class _BNActFn(torch.autograd.Function):
                     or not partials.is_contiguous():
                 raise ValueError("batch_norm_act: partials must be a contiguous fp32 [rows, 2, C] tensor")
             ws = _scratch(dev, max(nb, 512) * 2 * C)
-            rc = lib.dtf_bn_fwd_train_stats(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma),
-                                            _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]),
-                                            _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
-                                            _lib.ptr(partials), int(partials.shape[0]), _lib.ptr(ws), _lib.ptr(mask),
-                                            ctypes.c_longlong(M), C, ctypes.c_float(eps), ctypes.c_float(momentum),
-                                            int(relu), _reduce_counters(dev, C), _lib.stream_ptr(dev))
+            if res_scale is not None:
+                rc = lib.dtf_bn_fwd_train_stats_rn(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma),
+                                                   _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var),
+                                                   _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]),
+                                                   _lib.ptr(stats[3]), _lib.ptr(partials), int(partials.shape[0]),
+                                                   _lib.ptr(ws), _lib.ptr(mask), ctypes.c_longlong(M), C,
+                                                   ctypes.c_float(eps), ctypes.c_float(momentum), int(relu),
+                                                   _reduce_counters(dev, C), _lib.ptr(res_scale), _lib.ptr(res_shift),
+                                                   _lib.stream_ptr(dev))
+            else:
+                rc = lib.dtf_bn_fwd_train_stats(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma),
+                                                _lib.ptr(beta), _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]),
+                                                _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
+                                                _lib.ptr(partials), int(partials.shape[0]), _lib.ptr(ws), _lib.ptr(mask),
+                                                ctypes.c_longlong(M), C, ctypes.c_float(eps), ctypes.c_float(momentum),
+                                                int(relu), _reduce_counters(dev, C), _lib.stream_ptr(dev))
         else:
+            if res_scale is not None:
+                raise ValueError("batch_norm_act: a lazy residual needs the partial statistics of x")
             rc = lib.dtf_bn_fwd_train(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta),
                                       _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
                                       _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), _lib.ptr(mask),
@@ -273,7 +286,7 @@ class _BNActFn(torch.autograd.Function):
         if token is not None:
             token.masked_grad = (dy, dy._version, y)     # y holds the mask bytes saved by the forward pass
             dres = dy
-        return dx, dgb[0], dgb[1], None, None, None, None, None, dres, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, dres, None, None, None, None, None, None
 
 
 def batch_norm_deferred(x, gamma, beta, running_mean, running_var, momentum: float = 0.1, eps: float = 1e-5,
@@ -290,6 +303,31 @@ def batch_norm_deferred(x, gamma, beta, running_mean, running_var, momentum: flo
     if req is not None:
         setattr(alias, _REQ_ATTR, req)
     return DeferredNorm(alias, stats[2], stats[3], relu)
+
+
+def batch_norm_lazy(x, gamma, beta, running_mean, running_var, momentum: float = 0.1, eps: float = 1e-5,
+                    partials=None):
+    """Training-mode plain ``batch_norm(x)`` (no ReLU, no residual: the norm of a down-sampling branch) whose only
+    use is the residual input of a norm-add-ReLU: the statistics are finished from ``partials`` and a
+    :class:`DeferredNorm` is returned that :func:`batch_norm_act` takes as ``residual=``; its apply kernel then reads
+    this norm's INPUT and normalises it on the fly, so the branch's normalised tensor is never written or read back.
+    Backward is that of the ordinary plain norm (the alias is the autograd handle of its output, and carries the
+    :class:`ForkToken` through which the norm-add-ReLU hands over its incoming gradient with the mask bits).
+    ``None`` when the fast path does not apply (the caller then uses :func:`batch_norm_act`)."""
+    if not (_lazy_residual and partials is not None and _fast_path(x) and gamma.dtype == torch.float32
+            and torch.is_grad_enabled() and x.requires_grad):
+        return None
+    from . import conv as _conv
+    tok = ForkToken() if _conv._bn_grad_stats else None
+    alias, stats = _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, False, None, partials, None,
+                                  True, tok)
+    if tok is not None:
+        setattr(alias, _TOKEN_ATTR, tok)
+    return DeferredNorm(alias, stats[2], stats[3], False)
+
+
+# DTF_BN_LAZY_RESIDUAL=0 writes the down-sampling branch's normalised tensor as before (A/B switch)
+_lazy_residual = __import__("os").environ.get("DTF_BN_LAZY_RESIDUAL", "1") != "0"
 
 
 # Off by default: measured on MI355X (ResNet-50, batch 1024) the step is 90.9 ms with the deferred apply and 88.1 ms
@@ -309,6 +347,13 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, mo
                    eps: float = 1e-5, relu: bool = True, residual=None, partials=None):
     """``partials`` (training, fast path only): fp32 ``[rows, 2, C]`` partial sums ``sum(x)``, ``sum(x^2)`` over
     disjoint row sets covering ``x``, as produced by ``ops.conv.conv2d(..., bn_stats=True)``."""
+    lazy = None
+    if isinstance(residual, DeferredNorm):
+        if (training and relu and partials is not None and not residual.relu and _fast_path(x)
+                and gamma.dtype == torch.float32 and residual.tensor.shape == x.shape):
+            lazy, residual = residual, residual.tensor
+        else:
+            residual = residual.materialize()
     if _fast_path(x) and gamma.dtype == torch.float32:
         if training:
             # the request rides on the output tensor: ops.conv picks it up from its input (see GradStatsRequest)
@@ -317,8 +362,12 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, mo
             if req is not None and not relu and residual is None:
                 from . import conv as _conv
                 tok = ForkToken() if _conv._bn_grad_stats else None
-            y = _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual, partials, req,
-                               False, tok)
+            if lazy is not None:
+                y = _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual, partials,
+                                   req, False, tok, lazy.scale, lazy.shift)
+            else:
+                y = _BNActFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual, partials,
+                                   req, False, tok)
             if req is not None:
                 setattr(y, _REQ_ATTR, req)
             if tok is not None:
