@@ -214,6 +214,14 @@ DTF_API int dtf_col_sum_bf16(const void* g, float* out, int M, int N, long long 
   return (int)hipGetLastError();
 }
 
+// out[n] = sum over n_part rows of part ([n_part][N] fp32): the finishing step of column sums whose partial rows another
+// kernel wrote (the 256x256 GEMM's store phase)
+DTF_API int dtf_col_sum_finish(const float* part, float* out, int n_part, int N, hipStream_t stream) {
+  if (n_part <= 0 || N <= 0) return 0;
+  hipLaunchKernelGGL(col_sum_finish_kernel, dim3((N + 31) / 32), dim3(kBlock), 0, stream, part, out, n_part, N);
+  return (int)hipGetLastError();
+}
+
 // Channel padding of an NHWC bf16 image: out[p][0..Cp) = in[p][0..C) followed by zeros (Cp = 4 or a multiple of 8,
 // C < Cp). A first-layer convolution (1, 3 or 4 input channels) is fed through this so that every pixel (Cp = 8) or
 // every pixel pair (Cp = 4) is one aligned 16-byte operand chunk of the implicit-GEMM kernel. A thread writes one

@@ -63,6 +63,7 @@ struct G256Args {
   int k_per_split;       // multiple of TK
   int splits;
   long long* stamps;     // diagnostic: per output tile 4 wall-clock stamps (loop top, operands there, k-loop done, stores issued); null = off
+  float* col_sums;       // optional fp32 [4 * tiles_m][N]: column sums of the stored result over each wave's 64 rows
   int stagger;           // measurement hooks. > 0: 10 ns ticks between the start groups of the first round of workgroups; -1: no output stores
 };
 
@@ -251,11 +252,11 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
   // the main loop).
 #define WAIT_6S()                                                                              \
   do {                                                                                         \
-    if (s_out == 0) WAIT_VM(6); else if (s_out == 16) WAIT_VM(22); else WAIT_VM(38);           \
+    if (s_out == 0) WAIT_VM(6); else if (s_out == 16) WAIT_VM(22); else if (s_out == 24) WAIT_VM(30); else WAIT_VM(38); \
   } while (0)
 #define WAIT_8S()                                                                              \
   do {                                                                                         \
-    if (s_out == 0) WAIT_VM(8); else if (s_out == 16) WAIT_VM(24); else WAIT_VM(40);           \
+    if (s_out == 0) WAIT_VM(8); else if (s_out == 16) WAIT_VM(24); else if (s_out == 24) WAIT_VM(32); else WAIT_VM(40); \
   } while (0)
 #define ISSUE_OR_DRAIN_S(WHICH, TILE)                                                          \
   do {                                                                                         \
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
       while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
   }
-  int s_out = 0;     // output stores of the previous tile that may still be in flight (per wave: 0, 16 or 32)
+  int s_out = 0;     // output stores of the previous tile that may still be in flight (per wave: 0, 16, 24 or 32)
   if (it < nwg) { setup_tile(it); issue_prologue(); }
   const int it_step = flat_tile >= 0 ? nwg : (int)gridDim.x;     // a split-K workgroup owns one tile
   for (; it < nwg; it += it_step) {
@@ -404,9 +405,13 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
     asm volatile("" : "+s"(cm0e), "+s"(cn0e), "+v"(lane_e));
     const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
     const int col_e = (fq_e & 1) * 16 + (fq_e >> 1) * 8;     // first of the lane's 8 columns inside the wave's 32
-    auto epilogue = [&](auto act_c, auto cin_c) {
+    auto epilogue = [&](auto act_c, auto cin_c, auto cs_c) {
       constexpr int ACT = decltype(act_c)::value;     // 0 none, 1 relu, 2 gelu, 3 gelu + its derivative into C2
       constexpr int CIN = decltype(cin_c)::value;     // 0 none, 1 add Cin, 2 multiply by Cin
+      // column sums of the stored (rounded) result: the bias gradient of the layer whose output gradient this product
+      // is, summed per wave over its 64 rows of a quadrant and written as one partial row per (tile row, half, wave
+      // row); a finishing kernel adds the partial rows. Saves a pass over the result.
+      constexpr bool CS = decltype(cs_c)::value;
       // The combine input comes in by LDS-DMA, all 16 KiB of the wave's four quadrants at once, into the operand
       // buffers the main loop no longer needs: one exposed fetch latency instead of one per quadrant, and no
       // registers (holding even one quadrant ahead in registers spills). Only when no next tile's prologue
@@ -439,6 +444,11 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
           const int mq = cm0e + qi * 128 + wr * 64 + fr_e;
           const long long off0 = (long long)mq * g.ldc + n;
           u32x4 ci[4];
+          float cs[CS ? 8 : 1];
+          if (CS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[CS ? e : 0] = 0.f;
+          }
           if (CIN != 0 && !cin_dma) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -495,24 +505,51 @@ __global__ __launch_bounds__(kT256, 1) void gemm256_kernel(G256Args g) {
             if (inside) {
               *reinterpret_cast<u32x4*>(g.C + off0 + (long long)i * 16 * g.ldc) = val;
               if (ACT == 3) *reinterpret_cast<u32x4*>(g.C2 + off0 + (long long)i * 16 * g.ldc) = der;
+              if (CS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  cs[CS ? 2 * e : 0] += __uint_as_float(val[e] << 16);
+                  cs[CS ? 2 * e + 1 : 0] += __uint_as_float(val[e] & 0xffff0000u);
+                }
+              }
+            }
+          }
+          if (CS) {
+            // the 16 lanes of a DPP row hold the 16 rows of a slice for the same 8 columns: rotate-and-add
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float v = cs[CS ? e : 0];
+              v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+              v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+              v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+              v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+              cs[CS ? e : 0] = v;
+            }
+            if (fr_e == 0 && n < g.N) {
+              float* dst = g.col_sums + (long long)(((cm0e >> 8) * 2 + qi) * 2 + wr) * g.N + n;
+              *reinterpret_cast<f32x4*>(dst) = f32x4{cs[0], cs[CS ? 1 : 0], cs[CS ? 2 : 0], cs[CS ? 3 : 0]};
+              *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs[CS ? 4 : 0], cs[CS ? 5 : 0], cs[CS ? 6 : 0], cs[CS ? 7 : 0]};
             }
           }
         }
     };
     using std::integral_constant;
+    using no_cs = std::false_type;
     if (g.Cin) {
-      if (g.cin_mode == 2) epilogue(integral_constant<int, 0>{}, integral_constant<int, 2>{});
-      else epilogue(integral_constant<int, 0>{}, integral_constant<int, 1>{});
-    } else if (g.act == 0) epilogue(integral_constant<int, 0>{}, integral_constant<int, 0>{});
-    else if (g.act == 1) epilogue(integral_constant<int, 1>{}, integral_constant<int, 0>{});
-    else if (g.act == 2) epilogue(integral_constant<int, 2>{}, integral_constant<int, 0>{});
-    else epilogue(integral_constant<int, 3>{}, integral_constant<int, 0>{});
+      if (g.cin_mode == 2) {
+        if (g.col_sums) epilogue(integral_constant<int, 0>{}, integral_constant<int, 2>{}, std::true_type{});
+        else epilogue(integral_constant<int, 0>{}, integral_constant<int, 2>{}, no_cs{});
+      } else epilogue(integral_constant<int, 0>{}, integral_constant<int, 1>{}, no_cs{});
+    } else if (g.act == 0) epilogue(integral_constant<int, 0>{}, integral_constant<int, 0>{}, no_cs{});
+    else if (g.act == 1) epilogue(integral_constant<int, 1>{}, integral_constant<int, 0>{}, no_cs{});
+    else if (g.act == 2) epilogue(integral_constant<int, 2>{}, integral_constant<int, 0>{}, no_cs{});
+    else epilogue(integral_constant<int, 3>{}, integral_constant<int, 0>{}, no_cs{});
     // a full tile issued exactly 16 (32 with the derivative output) stores per wave after the next tile's prologue:
     // the counted waits of that tile's first K-tiles let them fly. An edge tile skips stores lane by lane and wave
     // by wave, so its count is unknown: drain.
     if (next < nwg) {
       if (cm0 + TM <= g.M && cn0 + TN <= g.N && g.stagger != -1) {
-        s_out = (!g.Cin && g.act == 3) ? 32 : 16;
+        s_out = (!g.Cin && g.act == 3) ? 32 : (g.Cin && g.cin_mode == 2 && g.col_sums) ? 24 : 16;
       } else {
         WAIT_VM(0);
         s_out = 0;
@@ -553,9 +590,12 @@ extern "C" int dtf_splitk_reduce(const float* W, void* C, const void* bias, int 
 // splits > 1: workspace holds splits * M * N floats. cin: optional bf16 tensor laid out like C, added to
 // (cin_mode 1) or multiplied into (cin_mode 2) the result. Returns -9 when the shape does not qualify (the
 // caller then uses dtf_gemm_bf16).
-DTF_API int dtf_gemm256_ex(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+// col_sums (only with cin_mode 2, a full-width result: N % 8 == 0): fp32 [4 * ceil(M / 256)][N] partial rows of the
+// column sums of the stored result (rows past M contribute nothing); dtf_col_sum_finish adds them.
+DTF_API int dtf_gemm256_cs(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                            long long lda, long long ldb, long long ldc, int bias_dtype, int act, int splits,
-                           void* workspace, const void* cin, int cin_mode, void* c2, hipStream_t stream) {
+                           void* workspace, const void* cin, int cin_mode, void* c2, float* col_sums,
+                           hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (K % TK || N % 8 || lda % 8 || ldb % 8 || ldc % 8 || M < 8 || N < 8) return -9;
   if (layout == 2 && M % 8) return -9;
@@ -590,6 +630,8 @@ DTF_API int dtf_gemm256_ex(int layout, const void* A, const void* B, void* C, co
   g.W = (float*)workspace; g.k_per_split = kps; g.splits = splits; g.Cin = (const unsigned short*)cin;
   g.cin_mode = cin ? cin_mode : 0; g.C2 = (unsigned short*)c2;
   g.stamps = g_stamps256;
+  g.col_sums = (cin && cin_mode == 2) ? col_sums : nullptr;
+  if (col_sums && !g.col_sums) return -9;
   g.stagger = g_stagger256;
   // persistent: one workgroup per CU (the kernel takes the whole LDS), each walking its share of tiles
   const int nwg = g.tiles_m * g.tiles_n;
@@ -603,6 +645,13 @@ DTF_API int dtf_gemm256_ex(int layout, const void* A, const void* B, void* C, co
   }
   if (splits > 1) return dtf_splitk_reduce((const float*)workspace, C, bias, bias_dtype, act, 0, splits, M, N, ldc, stream);
   return (int)hipGetLastError();
+}
+
+DTF_API int dtf_gemm256_ex(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                           long long lda, long long ldb, long long ldc, int bias_dtype, int act, int splits,
+                           void* workspace, const void* cin, int cin_mode, void* c2, hipStream_t stream) {
+  return dtf_gemm256_cs(layout, A, B, C, bias, M, N, K, lda, ldb, ldc, bias_dtype, act, splits, workspace, cin, cin_mode,
+                        c2, nullptr, stream);
 }
 
 DTF_API int dtf_gemm256(int layout, const void* A, const void* B, void* C, const void* bias, int M, int N, int K,

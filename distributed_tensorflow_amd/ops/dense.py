@@ -231,6 +231,10 @@ class _LinearForkFn(_LinearFn):
         return _LinearFn.backward(ctx, gy, g_alias)
 
 
+# DTF_FFN_BIAS_GRAD_FUSED=0: the feed-forward block's first bias gradient from a column-sum pass of its own (A/B switch)
+_fused_bias_grad = __import__("os").environ.get("DTF_FFN_BIAS_GRAD_FUSED", "1") != "0"
+
+
 class _FfnForkFn(torch.autograd.Function):
     """``(gelu(x W1^T + b1) W2^T + b2, alias of x)`` as one node, so that the GELU never runs as a kernel of
     its own: the first GEMM's epilogue writes ``h = gelu(pre)`` and ``d = gelu'(pre)``, and the data-gradient
@@ -261,9 +265,16 @@ class _FfnForkFn(torch.autograd.Function):
         M, Fd = h.shape
         gw2 = _gemm.gemm_tn(g2, h) if ctx.needs_input_grad[3] else None
         gb2 = _bias_grad(gy, g2, ctx.bias_dtypes[1]) if ctx.needs_input_grad[4] else None
-        g1 = _gemm.gemm256(_gemm.NN, g2, w2, M, Fd, g2.shape[1], mul=d)            # (g2 W2) * gelu'(pre)
+        # (g2 W2) * gelu'(pre); its column sums (the first layer's bias gradient) come out of the same store phase
+        gb1 = None
+        if ctx.needs_input_grad[2] and _fused_bias_grad:
+            g1, gb1 = _gemm.gemm256(_gemm.NN, g2, w2, M, Fd, g2.shape[1], mul=d, col_sum=True)
+            gb1 = gb1.to(ctx.bias_dtypes[0])
+        else:
+            g1 = _gemm.gemm256(_gemm.NN, g2, w2, M, Fd, g2.shape[1], mul=d)
+            if ctx.needs_input_grad[2]:
+                gb1 = _gemm.col_sum(g1, dtype=ctx.bias_dtypes[0])
         gw1 = _gemm.gemm_tn(g1, x2) if ctx.needs_input_grad[1] else None
-        gb1 = _gemm.col_sum(g1, dtype=ctx.bias_dtypes[0]) if ctx.needs_input_grad[2] else None
         gx = None
         if ctx.needs_input_grad[0]:
             add = None

@@ -219,11 +219,14 @@ def _big_ok(M: int, N: int, K: int) -> bool:
 
 def gemm256(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, bias=None, activation=None,
             out=None, splits: int = 1, add: torch.Tensor | None = None, mul: torch.Tensor | None = None,
-            grad_out: torch.Tensor | None = None) -> torch.Tensor:
+            grad_out: torch.Tensor | None = None, col_sum: bool = False):
     """``act(op(a) @ op(b) + bias)`` on the 256x256x64 LDS-DMA kernel (``csrc/kernels/gemm256.hip``);
     layouts as in this module (NT, NN, TN). ``splits`` > 1 splits the contraction (weight gradients).
     ``add`` / ``mul``: bf16 tensor laid out like the result, added to / multiplied into it in the epilogue.
-    ``grad_out`` (with ``activation="gelu"``): receives ``gelu'(pre-activation)``."""
+    ``grad_out`` (with ``activation="gelu"``): receives ``gelu'(pre-activation)``.
+    ``col_sum=True`` (with ``mul``): returns ``(result, fp32 column sums of the result)``; the store phase sums the
+    rounded values it writes per wave and a finishing kernel adds the partial rows (the bias gradient of the layer whose
+    output gradient the product is, without a pass over the result)."""
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     bias_dtype = _lib.dtype_code(bias.dtype) if bias is not None else 0
@@ -237,12 +240,24 @@ def gemm256(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: in
     if add is not None and mul is not None:
         raise ValueError("gemm256: add= and mul= are exclusive")
     cin = add if add is not None else mul
-    rc = _lib.kernels().dtf_gemm256_ex(layout, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(bias), M, N, K,
+    parts = None
+    if col_sum:
+        if mul is None or splits != 1:
+            raise ValueError("gemm256: col_sum=True needs mul= and no split-K")
+        parts = torch.empty((4 * ((M + 255) // 256), N), dtype=torch.float32, device=a.device)
+        if M % 256:
+            parts.zero_()                 # waves whose rows lie past M write nothing
+    rc = _lib.kernels().dtf_gemm256_cs(layout, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(bias), M, N, K,
                                        ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
                                        ctypes.c_longlong(out.stride(0)), bias_dtype, act, splits,
                                        _lib.ptr(ws), _lib.ptr(cin), 2 if mul is not None else 1, _lib.ptr(grad_out),
-                                       _lib.stream_ptr(a.device))
+                                       _lib.ptr(parts), _lib.stream_ptr(a.device))
     _lib.check(rc, "gemm256")
+    if col_sum:
+        sums = torch.empty(N, dtype=torch.float32, device=a.device)
+        _lib.check(_lib.kernels().dtf_col_sum_finish(_lib.ptr(parts), _lib.ptr(sums), int(parts.shape[0]), N,
+                                                     _lib.stream_ptr(a.device)), "col_sum_finish")
+        return out, sums
     return out
 
 

@@ -1628,3 +1628,22 @@ def test_general_convolution_with_more_than_65535_row_tiles():
     y = conv.conv2d(x, w, 1, 1)
     ref = torch.nn.functional.conv2d(x, w, None, 1, 1)
     torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(33000, 768, 256), (16640, 1280, 192), (2000, 520, 128)])
+def test_gemm256_multiply_epilogue_with_column_sums(shape):
+    """The multiply epilogue also returns the column sums of what it stores (full tiles, edge tiles, several tiles per
+    workgroup): equal to a sum over the stored bf16 result, and the result itself unchanged by the option."""
+    from distributed_tensorflow_amd.ops import gemm
+    M, N, K = shape
+    torch.manual_seed(M + N)
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    bt = torch.randn(K, N, device=DEV).bfloat16()
+    cin = torch.randn(M, N, device=DEV).bfloat16()
+    plain = gemm.gemm256(gemm.NN, a, bt, M, N, K, mul=cin)
+    out, sums = gemm.gemm256(gemm.NN, a, bt, M, N, K, mul=cin, col_sum=True)
+    assert torch.equal(out, plain)
+    ref = out.double().sum(0)
+    assert torch.allclose(sums.double(), ref, rtol=1e-4, atol=1e-2 * float(ref.abs().max())), float((sums.double() - ref).abs().max())
+    out2, sums2 = gemm.gemm256(gemm.NN, a, bt, M, N, K, mul=cin, col_sum=True)
+    assert torch.equal(out, out2) and torch.equal(sums, sums2)
