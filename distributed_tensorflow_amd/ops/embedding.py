@@ -83,6 +83,10 @@ def _table_grad(g, ids, n_rows, row_base=0):
     return out
 
 
+# DTF_EMB_ONEHOT=0: gradients of tables of a few rows through the sorted-run kernel (A/B switch)
+_onehot_small = __import__("os").environ.get("DTF_EMB_ONEHOT", "1") != "0"
+
+
 class _EmbFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, ids, pos, typ, tt):
@@ -114,7 +118,19 @@ class _EmbFn(torch.autograd.Function):
             dpos[:period] = d
             dpos = dpos.to(dt)
         if T and ctx.needs_input_grad[3]:
-            dtyp = _table_grad(g2, tt, T).to(dt)
+            if (_onehot_small and g2.is_cuda and g2.dtype == torch.bfloat16 and T <= 64 and g2.shape[0] % 8 == 0
+                    and g2.shape[1] % 8 == 0):
+                # a table of a few rows (token types): every id repeats tens of thousands of times, so the sorted-run
+                # kernel would walk runs of 128 rows thread by thread and combine 500 pieces per row with atomics
+                # (~300 us for 65536 tokens). one_hot(ids)^T @ g is the same sum as a split-K product (fp32
+                # accumulation of the bf16 rows, deterministic): ~20 us.
+                from . import gemm as _gemm
+                Tp = -(-T // 8) * 8
+                oh = torch.zeros((g2.shape[0], Tp), dtype=torch.bfloat16, device=g2.device)
+                oh.scatter_(1, tt.reshape(-1, 1).long(), 1.0)
+                dtyp = _gemm.gemm_tn(oh, g2.contiguous(), out_dtype=torch.float32)[:T].to(dt)
+            else:
+                dtyp = _table_grad(g2, tt, T).to(dt)
         return dtab, None, dpos, dtyp, None
 
 
