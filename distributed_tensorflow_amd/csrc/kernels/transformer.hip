@@ -35,7 +35,9 @@ __device__ __forceinline__ void t_ldp<unsigned short>(const unsigned short* p, f
 // ------------------------------------------------------------------------------ LayerNorm
 // y = LN(x (+ res)) * gamma + beta ; optionally writes s = x + res (the new residual stream).
 // stats[row] = {mean, rstd}. H % 8 == 0, H <= 64 * 8 * CH.
-template <int CH, typename P>
+// A wave takes RW consecutive rows and requests all of their chunks (non-temporal: nothing here is read twice) and the
+// coefficients before it converts the first.
+template <int CH, typename P, int RW>
 __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const unsigned short* __restrict__ x,
                                                         const unsigned short* __restrict__ res,
                                                         const P* __restrict__ gamma, const P* __restrict__ beta,
@@ -43,52 +45,73 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const unsigned short* __
                                                         unsigned short* __restrict__ sum_out,
                                                         float* __restrict__ stats, long long rows, int H, float eps) {
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const long long row0 = ((long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * RW;
+  if (row0 >= rows) return;
   const int nch = H >> 3;
-  float v[CH][8];
-  float s = 0.f;
+  u16x8 xr[RW][CH], rr[RW][CH];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch && row0 + r < rows) {
+        xr[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(x + (row0 + r) * H + ch * 8));
+        if (res) rr[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(res + (row0 + r) * H + ch * 8));
+      }
+    }
+  // the coefficients are requested with the activations: after the statistics they would be one more exposed latency
+  float gm[CH][8], bt[CH][8];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int ch = lane + 64 * c;
-    if (ch < nch) {
-      t_ld8(x + row * H + ch * 8, v[c]);
-      if (res) {
-        float r[8];
-        t_ld8(res + row * H + ch * 8, r);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[c][k] += r[k];
-      }
-      if (sum_out) {
-        t_st8(sum_out + row * H + ch * 8, v[c]);
-        // normalise what later layers will read back: the bf16-rounded sum
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[c][k] = bf16_to_f32(f32_to_bf16(v[c][k]));
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) s += v[c][k];
-    }
+    if (ch < nch) { t_ldp<P>(gamma + ch * 8, gm[c]); t_ldp<P>(beta + ch * 8, bt[c]); }
   }
-  const float mean = wave_sum(s) / (float)H;
-  float q = 0.f;
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    if (lane + 64 * c < nch) {
+  for (int r = 0; r < RW; ++r) {
+    const long long row = row0 + r;
+    if (row >= rows) break;
+    float v[CH][8];
+    float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { const float d = v[c][k] - mean; q = fmaf(d, d, q); }
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[c][k] = bf16_to_f32(xr[r][c][k]);
+        if (res) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[c][k] += bf16_to_f32(rr[r][c][k]);
+        }
+        if (sum_out) {
+          t_st8(sum_out + row * H + ch * 8, v[c]);
+          // normalise what later layers will read back: the bf16-rounded sum
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[c][k] = bf16_to_f32(f32_to_bf16(v[c][k]));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[c][k];
+      }
     }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
-  if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int ch = lane + 64 * c;
-    if (ch < nch) {
-      float g[8], b[8], o[8];
-      t_ldp<P>(gamma + ch * 8, g); t_ldp<P>(beta + ch * 8, b);
+    for (int c = 0; c < CH; ++c) {
+      if (lane + 64 * c < nch) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = fmaf((v[c][k] - mean) * rstd, g[k], b[k]);
-      t_st8(y + row * H + ch * 8, o);
+        for (int k = 0; k < 8; ++k) { const float d = v[c][k] - mean; q = fmaf(d, d, q); }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+    if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = fmaf((v[c][k] - mean) * rstd, gm[c][k], bt[c][k]);
+        t_st8(y + row * H + ch * 8, o);
+      }
     }
   }
 }
@@ -299,18 +322,27 @@ __global__ __launch_bounds__(kBlock) void softmax_bwd_kernel(const unsigned shor
 // ------------------------------------------------------------------------------ C ABI
 static inline int ch_for(int n) { return n <= 512 ? 1 : n <= 1024 ? 2 : n <= 2048 ? 4 : n <= 4096 ? 8 : 0; }
 
+static int g_ln_fwd_rows = 0;   // rows per wave of the LayerNorm forward kernel (0 = by row width; 1, 2, 4: measurement hook)
+DTF_API void dtf_ln_set_fwd_rows(int n) { if (n == 0 || n == 1 || n == 2 || n == 4) g_ln_fwd_rows = n; }
+
 DTF_API int dtf_ln_fwd(const void* x, const void* res, const void* gamma, const void* beta, void* y, void* sum_out,
                        float* stats, long long rows, int H, float eps, int param_dtype, hipStream_t stream) {
   if (rows <= 0) return 0;
   const int ch = ch_for(H);
   if (H % 8 || ch == 0) return -1;
-  const dim3 grid((unsigned)((rows + 3) / 4));
-#define LN(CHN, P)                                                                                           \
-  hipLaunchKernelGGL((ln_fwd_kernel<CHN, P>), grid, dim3(kBlock), 0, stream, (const unsigned short*)x,      \
+  // rows per wave: rows of at most 4 chunks per lane are taken in pairs (768 wide, 196,608 rows: 212 us against 219 with
+  // one and 220 with four: the kernel stays near 4.2 TB/s whatever the shape of its requests); g_ln_fwd_rows overrides
+  const int rw = g_ln_fwd_rows ? g_ln_fwd_rows : (ch <= 4 ? 2 : 1);
+  const long long per_block = 4LL * rw;
+  const dim3 grid((unsigned)((rows + per_block - 1) / per_block));
+#define LN(CHN, P, RWN)                                                                                      \
+  hipLaunchKernelGGL((ln_fwd_kernel<CHN, P, RWN>), grid, dim3(kBlock), 0, stream, (const unsigned short*)x, \
                      (const unsigned short*)res, (const P*)gamma, (const P*)beta, (unsigned short*)y,       \
                      (unsigned short*)sum_out, stats, rows, H, eps)
-#define LN_D(CHN) do { if (param_dtype == 0) LN(CHN, float); else LN(CHN, unsigned short); } while (0)
+#define LN_R(CHN, P) do { if (rw == 4 && CHN <= 2) LN(CHN, P, 4); else if (rw >= 2 && CHN <= 4) LN(CHN, P, 2); else LN(CHN, P, 1); } while (0)
+#define LN_D(CHN) do { if (param_dtype == 0) LN_R(CHN, float); else LN_R(CHN, unsigned short); } while (0)
   switch (ch) { case 1: LN_D(1); break; case 2: LN_D(2); break; case 4: LN_D(4); break; default: LN_D(8); }
+#undef LN_R
 #undef LN_D
 #undef LN
   return (int)hipGetLastError();
