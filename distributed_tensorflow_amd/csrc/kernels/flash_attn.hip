@@ -48,6 +48,7 @@ struct AttnArgs {
   unsigned short* dqkv;        // bwd: [B, S, 3, nh, 64]
   int B, S, nh;
   float scale;                 // 1 / sqrt(hd)
+  float* col_parts;            // bwd, optional: fp32 [B * S / 32][3 * nh * 64] column sums of dqkv per wave (32 rows)
 };
 
 // row image: [64 rows][128 B], 16-byte chunks XOR-swizzled for conflict-free ds_read_b128 fragments
@@ -151,6 +152,33 @@ __device__ __forceinline__ void store_tr_img(char* img, const TileRegs& r, int t
   for (int u = 0; u < 2; ++u) {
     const int p = u * 256 + tid, row = p >> 3, chunk = p & 7;
     *reinterpret_cast<u32x4*>(img + tr_off(row, chunk)) = r.v[u];
+  }
+}
+
+
+// Column sums of what a wave stores (its 32 rows x 64 columns of dQ, dK or dV, rounded to bf16 like the stores): the
+// bias gradient of the fused QKV projection, which then needs no pass over dqkv. v[db][rb] holds, per lane, 4 consecutive
+// columns (db * 16 + g * 4 ...) of row rb * 16 + fr: the two row blocks add in the lane, the 16 rows of a block across
+// the DPP row (rotate-and-add), and the lane with fr == 0 writes the wave's partial row.
+__device__ __forceinline__ void wave_col_sums(const u32x2 (&w)[4][2], float* dst, int fr, int g) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      t[2 * e] = __uint_as_float(w[db][0][e] << 16) + __uint_as_float(w[db][1][e] << 16);
+      t[2 * e + 1] = __uint_as_float(w[db][0][e] & 0xffff0000u) + __uint_as_float(w[db][1][e] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = t[e];
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+      t[e] = v;
+    }
+    if (fr == 0) *reinterpret_cast<f32x4*>(dst + db * 16 + g * 4) = t;
   }
 }
 
@@ -413,14 +441,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(AttnArgs a) {
     __syncthreads();
   }
   unsigned short* dqp = a.dqkv + ((long long)b * a.S * 3) * a.nh * HD + h * HD;
+  u32x2 wq[4][2];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     unsigned short* row = dqp + (long long)(q0 + qb * 16 + fr) * ld;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
-      *reinterpret_cast<u32x2*>(row + db * 16 + g * 4) = pack_row4(dq[db][qb] * a.scale);
+      wq[db][qb] = pack_row4(dq[db][qb] * a.scale);
+      *reinterpret_cast<u32x2*>(row + db * 16 + g * 4) = wq[db][qb];
     }
   }
+  if (a.col_parts)
+    wave_col_sums(wq, a.col_parts + ((long long)b * (a.S >> 5) + (q0 >> 5)) * (3 * a.nh * HD) + h * HD, fr, g);
 }
 
 // ------------------------------------------------------------------------------ backward: dK, dV
@@ -550,14 +582,22 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkdv_kernel(AttnArgs a) {
   }
   unsigned short* dkp = a.dqkv + ((long long)b * a.S * 3 + 1) * a.nh * HD + h * HD;
   unsigned short* dvp = dkp + (long long)a.nh * HD;
+  u32x2 wk[4][2], wv[4][2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     const long long off = (long long)(k0 + kb * 16 + fr) * ld;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
-      *reinterpret_cast<u32x2*>(dkp + off + db * 16 + g * 4) = pack_row4(dk[db][kb] * a.scale);
-      *reinterpret_cast<u32x2*>(dvp + off + db * 16 + g * 4) = pack_row4(dv[db][kb]);
+      wk[db][kb] = pack_row4(dk[db][kb] * a.scale);
+      wv[db][kb] = pack_row4(dv[db][kb]);
+      *reinterpret_cast<u32x2*>(dkp + off + db * 16 + g * 4) = wk[db][kb];
+      *reinterpret_cast<u32x2*>(dvp + off + db * 16 + g * 4) = wv[db][kb];
     }
+  }
+  if (a.col_parts) {
+    float* dst = a.col_parts + ((long long)b * (a.S >> 5) + (k0 >> 5)) * (3 * a.nh * HD) + h * HD;
+    wave_col_sums(wk, dst + a.nh * HD, fr, g);
+    wave_col_sums(wv, dst + 2 * a.nh * HD, fr, g);
   }
 }
 
@@ -579,17 +619,22 @@ DTF_API int dtf_flash_attn_fwd(const void* qkv, const float* bias, void* out, fl
 }
 
 // dqkv [B, S, 3, nh, 64] from dout [B, S, nh, 64], the forward's out and lse; delta: fp32 [B, nh, S] scratch.
-DTF_API int dtf_flash_attn_bwd(const void* qkv, const float* bias, const void* out, const float* lse, const void* dout,
-                               float* delta, void* dqkv, int B, int S, int nh, int hd, float scale,
-                               hipStream_t stream) {
+extern "C" int dtf_col_sum_finish(const float* part, float* out, int n_part, int N, hipStream_t stream);
+
+// col_parts (optional): fp32 [B * S / 32][3 * nh * 64] scratch; col_sums: fp32 [3 * nh * 64] receives the column sums of
+// dqkv viewed as [B * S, 3 * nh * 64] (the bias gradient of the fused QKV projection).
+DTF_API int dtf_flash_attn_bwd_cs(const void* qkv, const float* bias, const void* out, const float* lse, const void* dout,
+                                  float* delta, void* dqkv, int B, int S, int nh, int hd, float scale, float* col_parts,
+                                  float* col_sums, hipStream_t stream) {
   if (!attn_shape_ok(B, S, nh, hd)) return -9;
+  if ((col_parts != nullptr) != (col_sums != nullptr)) return -1;
   const long long rows = (long long)B * S * nh;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, stream,
                      (const unsigned short*)out, (const unsigned short*)dout, delta, B, S, nh);
   AttnArgs a = {};
   a.qkv = (const unsigned short*)qkv; a.bias = bias; a.lse = const_cast<float*>(lse);
   a.dout = (const unsigned short*)dout; a.delta = delta; a.dqkv = (unsigned short*)dqkv;
-  a.B = B; a.S = S; a.nh = nh; a.scale = scale;
+  a.B = B; a.S = S; a.nh = nh; a.scale = scale; a.col_parts = col_parts;
   if (bias) {
     hipLaunchKernelGGL(flash_bwd_dq_kernel<true>, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(flash_bwd_dkdv_kernel<true>, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
@@ -597,5 +642,12 @@ DTF_API int dtf_flash_attn_bwd(const void* qkv, const float* bias, const void* o
     hipLaunchKernelGGL(flash_bwd_dq_kernel<false>, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(flash_bwd_dkdv_kernel<false>, dim3(S / QB, nh, B), dim3(256), 0, stream, a);
   }
+  if (col_parts) return dtf_col_sum_finish(col_parts, col_sums, B * (S >> 5), 3 * nh * HD, stream);
   return (int)hipGetLastError();
+}
+
+DTF_API int dtf_flash_attn_bwd(const void* qkv, const float* bias, const void* out, const float* lse, const void* dout,
+                               float* delta, void* dqkv, int B, int S, int nh, int hd, float scale,
+                               hipStream_t stream) {
+  return dtf_flash_attn_bwd_cs(qkv, bias, out, lse, dout, delta, dqkv, B, S, nh, hd, scale, nullptr, nullptr, stream);
 }

@@ -57,10 +57,20 @@ class _FlashFn(torch.autograd.Function):
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(B, nh, S, dtype=torch.float32, device=qkv.device)
-        rc = _lib.kernels().dtf_flash_attn_bwd(_lib.ptr(qkv), _lib.ptr(bias if ctx.has_bias else None), _lib.ptr(out),
-                                               _lib.ptr(lse), _lib.ptr(dout), _lib.ptr(delta), _lib.ptr(dqkv), B, S, nh,
-                                               hd, ctypes.c_float(1.0 / math.sqrt(hd)), _lib.stream_ptr(qkv.device))
+        # the kernels also sum the columns of the dqkv they store (per wave, finished by one small kernel): the bias
+        # gradient of the fused QKV projection, offered to that layer's backward under dqkv's address
+        from . import layernorm as _ln
+        parts = sums = None
+        if _ln.hand_over_enabled():
+            parts = torch.empty((B * (S // 32), 3 * nh * hd), dtype=torch.float32, device=qkv.device)
+            sums = torch.empty(3 * nh * hd, dtype=torch.float32, device=qkv.device)
+        rc = _lib.kernels().dtf_flash_attn_bwd_cs(_lib.ptr(qkv), _lib.ptr(bias if ctx.has_bias else None), _lib.ptr(out),
+                                                  _lib.ptr(lse), _lib.ptr(dout), _lib.ptr(delta), _lib.ptr(dqkv), B, S,
+                                                  nh, hd, ctypes.c_float(1.0 / math.sqrt(hd)), _lib.ptr(parts),
+                                                  _lib.ptr(sums), _lib.stream_ptr(qkv.device))
         _lib.check(rc, "flash_attn_bwd")
+        if sums is not None:
+            _ln.offer_col_sum(dqkv, sums)
         return dqkv, None
 
 

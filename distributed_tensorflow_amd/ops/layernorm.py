@@ -34,6 +34,18 @@ _handed: dict = {}
 _hand_over = __import__("os").environ.get("DTF_LN_BIAS_GRAD", "1") != "0"
 
 
+def hand_over_enabled() -> bool:
+    return _hand_over
+
+
+def offer_col_sum(t: torch.Tensor, cs: torch.Tensor) -> None:
+    """Leaves the fp32 column sums ``cs`` of ``t`` (viewed as ``[rows, cs.numel()]``) for the layer whose output
+    gradient ``t`` is (another producer than the LayerNorm backward: the fused attention's backward kernels)."""
+    while len(_handed) >= 2:
+        _handed.pop(next(iter(_handed)))
+    _handed[t.data_ptr()] = (t, t._version, cs)
+
+
 def take_col_sum(g: torch.Tensor):
     """fp32 column sums of ``g`` (viewed as ``[rows, H]``) when ``g`` is, untouched, the input gradient the last
     LayerNorm backward produced; ``None`` otherwise."""

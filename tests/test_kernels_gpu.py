@@ -1647,3 +1647,32 @@ def test_gemm256_multiply_epilogue_with_column_sums(shape):
     assert torch.allclose(sums.double(), ref, rtol=1e-4, atol=1e-2 * float(ref.abs().max())), float((sums.double() - ref).abs().max())
     out2, sums2 = gemm.gemm256(gemm.NN, a, bt, M, N, K, mul=cin, col_sum=True)
     assert torch.equal(out, out2) and torch.equal(sums, sums2)
+
+
+def test_flash_backward_offers_the_qkv_bias_gradient():
+    """The fused attention's backward kernels sum the columns of the dqkv they store; the QKV projection's backward
+    takes those sums as its bias gradient instead of a pass over dqkv."""
+    from distributed_tensorflow_amd.ops import attention as A, dense, gemm, layernorm as LN
+    torch.manual_seed(5)
+    B, S, nh, hd, H = 3, 256, 4, 64, 256
+    x = torch.randn(B, S, H, device=DEV).bfloat16()
+    w = (torch.randn(3 * nh * hd, H, device=DEV) * 0.05).bfloat16().requires_grad_(True)
+    bias = torch.zeros(3 * nh * hd, device=DEV).bfloat16().requires_grad_(True)
+    dout = torch.randn(B, S, nh, hd, device=DEV).bfloat16()
+    grads, passes = {}, {}
+    real = gemm.col_sum
+    for on in (True, False):
+        calls = []
+        gemm.col_sum = lambda g, dtype=torch.float32: (calls.append(tuple(g.shape)), real(g, dtype))[1]
+        LN._hand_over = on
+        try:
+            w.grad = bias.grad = None
+            qkv = dense.linear(x, w, bias).view(B, S, 3, nh, hd)
+            A.self_attention(qkv, None).backward(dout)
+        finally:
+            gemm.col_sum = real
+            LN._hand_over = True
+        grads[on], passes[on] = bias.grad.float().clone(), len(calls)
+    assert passes[True] == 0 and passes[False] == 1
+    scale = float(grads[False].abs().max())
+    assert torch.allclose(grads[True], grads[False], rtol=2e-2, atol=2e-2 * scale), float((grads[True] - grads[False]).abs().max())
