@@ -44,7 +44,7 @@ struct AttnArgs {
   unsigned short* out;         // fwd: [B, S, nh, 64]
   float* lse;                  // [B, nh, S] log2-sum-exp of the scaled scores
   const unsigned short* dout;  // bwd: [B, S, nh, 64]
-  const float* delta;          // bwd: [B, nh, S] rowsum(dO * O)
+  float* delta;                // bwd: [B, nh, S] rowsum(dO * O): written by the dQ kernel, read by the dK / dV kernel
   unsigned short* dqkv;        // bwd: [B, S, 3, nh, 64]
   int B, S, nh;
   float scale;                 // 1 / sqrt(hd)
@@ -362,7 +362,22 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(AttnArgs a) {
       dof[qb][ks] = *reinterpret_cast<const bf16x8_t*>(dop + (long long)q * ldo + ks * 32 + g * 8);
     }
     lse[qb] = a.lse[((long long)b * a.nh + h) * a.S + q];
-    dl[qb] = a.delta[((long long)b * a.nh + h) * a.S + q];
+    // delta[q] = sum_d dO[q, d] O[q, d]: the lane's 16 columns here, the other three column groups of the query two
+    // swaps away; written out for the dK / dV kernel, which runs after this one (no kernel of its own, and dO is
+    // read once less)
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(a.out + (long long)b * a.S * ldo + h * HD + (long long)q * ldo +
+                                                             ks * 32 + g * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) part = fmaf((float)of[k], (float)dof[qb][ks][k], part);
+    }
+    const SwapPair p16 = swap16(part);
+    const float half = p16.x + p16.y;
+    const SwapPair p32 = swap32(half);
+    dl[qb] = p32.x + p32.y;
+    if (g == 0) a.delta[((long long)b * a.nh + h) * a.S + q] = dl[qb];
   }
   f32x4 dq[4][2];
 #pragma unroll
@@ -628,11 +643,9 @@ DTF_API int dtf_flash_attn_bwd_cs(const void* qkv, const float* bias, const void
                                   float* col_sums, hipStream_t stream) {
   if (!attn_shape_ok(B, S, nh, hd)) return -9;
   if ((col_parts != nullptr) != (col_sums != nullptr)) return -1;
-  const long long rows = (long long)B * S * nh;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, stream,
-                     (const unsigned short*)out, (const unsigned short*)dout, delta, B, S, nh);
+  // (delta is computed and written by the dQ kernel, read by the dK / dV kernel launched after it)
   AttnArgs a = {};
-  a.qkv = (const unsigned short*)qkv; a.bias = bias; a.lse = const_cast<float*>(lse);
+  a.qkv = (const unsigned short*)qkv; a.bias = bias; a.lse = const_cast<float*>(lse); a.out = (unsigned short*)out;
   a.dout = (const unsigned short*)dout; a.delta = delta; a.dqkv = (unsigned short*)dqkv;
   a.B = B; a.S = S; a.nh = nh; a.scale = scale; a.col_parts = col_parts;
   if (bias) {
