@@ -634,7 +634,7 @@ DTF_API int dtf_flash_attn_fwd(const void* qkv, const float* bias, void* out, fl
 }
 
 // dqkv [B, S, 3, nh, 64] from dout [B, S, nh, 64], the forward's out and lse; delta: fp32 [B, nh, S] scratch.
-extern "C" int dtf_col_sum_finish(const float* part, float* out, int n_part, int N, hipStream_t stream);
+extern "C" int dtf_col_sum_finish(float* part, float* out, int n_part, int N, hipStream_t stream);
 
 // col_parts (optional): fp32 [B * S / 32][3 * nh * 64] scratch; col_sums: fp32 [3 * nh * 64] receives the column sums of
 // dqkv viewed as [B * S, 3 * nh * 64] (the bias gradient of the fused QKV projection).

@@ -103,6 +103,10 @@ def _padded_cols(n: int) -> int:
     return (n + 7) // 8 * 8
 
 
+# DTF_PADN_BIG=0: wide unaligned layers stay on the 128x128 kernel (A/B switch)
+_pad_big = __import__("os").environ.get("DTF_PADN_BIG", "1") != "0"
+
+
 class _LinearPadNFn(torch.autograd.Function):
     """bf16 layer whose output width is not a multiple of 8 (BERT's 30522-word vocabulary projection): the output
     lives in a buffer with rows padded to 16 bytes and the MFMA kernel runs all three products. Forward: rows of the
@@ -112,6 +116,16 @@ class _LinearPadNFn(torch.autograd.Function):
     whole chunks of the gradient against zero rows of the weight, and the weight gradient stores N rows."""
 
     @staticmethod
+    def _big(M, N, K) -> bool:
+        """Large products (the 30522-word projection over tens of thousands of positions) run on the 256x256 kernel
+        against a copy of the weight with zero rows up to the padded width (47 MB per step for BERT-base: 20 us,
+        against 646 -> ~1,000 TFLOP/s on 4.3 TFLOP of products); the padded width must then also be a whole number
+        of 64-deep K-tiles, since the data gradient contracts over it."""
+        Np = _padded_cols(N)
+        return (_pad_big and Np % 64 == 0 and K % 64 == 0 and _gemm.big_ok(M, Np, K) and _gemm.big_ok(M, K, Np)
+                and _gemm._big_splits(Np, K, M) > 0)
+
+    @staticmethod
     def forward(ctx, x, w, b):
         K, N = x.shape[-1], w.shape[0]
         x2 = x.reshape(-1, K)
@@ -119,16 +133,28 @@ class _LinearPadNFn(torch.autograd.Function):
             x2 = x2.contiguous()
         M, Np = x2.shape[0], _padded_cols(N)
         buf = torch.empty((M, Np), dtype=torch.bfloat16, device=x.device)
-        _gemm.gemm_raw(_gemm.NT, x2, w, buf, M, N, K, K, K, Np, bias=b)
+        ctx.big = _LinearPadNFn._big(M, N, K) and w.is_contiguous()
+        if ctx.big:
+            wp = torch.zeros((Np, K), dtype=w.dtype, device=w.device)
+            wp[:N].copy_(w)
+            bp = None
+            if b is not None:
+                bp = torch.zeros(Np, dtype=b.dtype, device=b.device)
+                bp[:N].copy_(b)
+            _gemm.gemm256(_gemm.NT, x2, wp, M, Np, K, bias=bp, out=buf)
+            w = wp
+        else:
+            _gemm.gemm_raw(_gemm.NT, x2, w, buf, M, N, K, K, K, Np, bias=b)
         ctx.bias_dtype = b.dtype if b is not None else None
         ctx.x_shape = x.shape
+        ctx.n_out = N
         ctx.save_for_backward(x2, w)
         return buf.view(*x.shape[:-1], Np)[..., :N]
 
     @staticmethod
     def backward(ctx, gy):
-        x2, w = ctx.saved_tensors
-        N, K = w.shape
+        x2, w = ctx.saved_tensors          # (big path: w is the zero-padded copy)
+        N, K = ctx.n_out, w.shape[1]
         M, Np = x2.shape[0], _padded_cols(N)
         g = gy.reshape(-1, N) if gy.dim() != 2 else gy
         # a [M, N] window of a buffer of exactly M rows of Np elements: the padded layout this function (and the
@@ -143,12 +169,18 @@ class _LinearPadNFn(torch.autograd.Function):
             full[:, :N].copy_(g)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty((M, K), dtype=torch.bfloat16, device=g.device)
-            _gemm.gemm_raw(_gemm.NN, full, w, gx, M, K, N, Np, K, K)
+            if ctx.big:
+                gx = _gemm.gemm256(_gemm.NN, full, w, M, K, Np)
+            else:
+                gx = torch.empty((M, K), dtype=torch.bfloat16, device=g.device)
+                _gemm.gemm_raw(_gemm.NN, full, w, gx, M, K, N, Np, K, K)
             gx = gx.reshape(ctx.x_shape)
         if ctx.needs_input_grad[1]:
-            gw = torch.empty((N, K), dtype=torch.bfloat16, device=g.device)
-            _gemm.gemm_raw(_gemm.TN, full, x2, gw, N, K, M, Np, K, K)
+            if ctx.big:
+                gw = _gemm.gemm256(_gemm.TN, full, x2, Np, K, M, splits=_gemm._big_splits(Np, K, M))[:N]
+            else:
+                gw = torch.empty((N, K), dtype=torch.bfloat16, device=g.device)
+                _gemm.gemm_raw(_gemm.TN, full, x2, gw, N, K, M, Np, K, K)
         if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
             gb = _gemm.col_sum(full, dtype=torch.float32)[:N].to(ctx.bias_dtype)
         return gx, gw, gb

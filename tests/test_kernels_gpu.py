@@ -684,7 +684,7 @@ def test_stem_norm_pool_takes_the_statistics_of_the_first_convolution():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [(300, 64, 1002), (1000, 768, 3054), (64, 128, 67)])
+@pytest.mark.parametrize("cfg", [(300, 64, 1002), (1000, 768, 3054), (64, 128, 67), (2048, 768, 30522)])
 def test_linear_unaligned_width_runs_on_the_bf16_kernel_with_padded_rows(cfg):
     """A bf16 layer whose width is not a multiple of 8 (BERT's vocabulary projection) followed by the fused loss:
     logits and their gradient stay in row-padded buffers; values and all gradients against an fp32 evaluation."""
