@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ forward
 // delta[b, h, q] = sum_d dO[b, q, h, d] * O[b, q, h, d]; one wave per 8 rows (8 lanes x 16 bytes per row)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* __restrict__ o,
                                                          const unsigned short* __restrict__ dout,
