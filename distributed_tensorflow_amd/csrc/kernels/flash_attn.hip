@@ -310,31 +310,6 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------ forward
-// delta[b, h, q] = sum_d dO[b, q, h, d] * O[b, q, h, d]; one wave per 8 rows (8 lanes x 16 bytes per row)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* __restrict__ o,
-                                                         const unsigned short* __restrict__ dout,
-                                                         float* __restrict__ delta, int B, int S, int nh) {
-  const long long rows = (long long)B * S * nh;
-  const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3;
-  const int c = threadIdx.x & 7;
-  float s = 0.f;
-  if (row < rows) {
-    const u16x8 x = *reinterpret_cast<const u16x8*>(o + row * HD + c * 8);
-    const u16x8 y = *reinterpret_cast<const u16x8*>(dout + row * HD + c * 8);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s = fmaf(bf16_to_f32(x[k]), bf16_to_f32(y[k]), s);
-  }
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-  if (row < rows && c == 0) {
-    const long long bs = row / nh;                 // (b * S + q)
-    const int h = (int)(row - bs * nh);
-    const long long bb = bs / S;
-    const int q = (int)(bs - bb * S);
-    delta[(bb * nh + h) * S + q] = s;
-  }
-}
-
 // ------------------------------------------------------------------------------ backward: dQ
 // Workgroup = 128 query rows of one (batch, head); loops over key tiles. Per tile: S^T = K Q^T and
 // dP^T = V dO^T (key on the accumulator row, query on the lane), P = exp2(S' - lse),
