@@ -338,6 +338,60 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(const unsigned sho
   }
 }
 
+// Two norms that share their incoming gradient -- the closing norm of a down-sampling block (input x) and the norm of
+// its down-sampling branch (input z), whose outputs were added before the ReLU: dx = A dy' + K x + C0 and
+// dz = A2 dy' + K2 z + C02 with dy' = dy masked by the block's mask bits. dy and the bits are read once for both.
+template <int R, bool NT>
+__global__ __launch_bounds__(kBlock) void bn_apply_bwd2_kernel(const unsigned short* __restrict__ x,
+                                                               const unsigned short* __restrict__ z,
+                                                               const unsigned short* __restrict__ dy,
+                                                               const unsigned char* __restrict__ mask,
+                                                               const float* __restrict__ coef,
+                                                               const float* __restrict__ coef2,
+                                                               unsigned short* __restrict__ dx,
+                                                               unsigned short* __restrict__ dz, long long M, int C) {
+  const int c8 = C >> 3;
+  const long long n8 = M * c8;
+  const bool fixed = (kBlock % c8) == 0;
+  for (long long base = (long long)blockIdx.x * (kBlock * R); base < n8; base += (long long)gridDim.x * (kBlock * R)) {
+    const long long i0 = base + threadIdx.x;
+    u16x8 xr[R], zr[R], gr[R];
+    unsigned mbits[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const long long i = i0 + k * kBlock;
+      if (i < n8) {
+        xr[k] = ldraw<NT>(x + i * 8);
+        zr[k] = ldraw<NT>(z + i * 8);
+        gr[k] = ldraw<NT>(dy + i * 8);
+        mbits[k] = mask[i];
+      }
+    }
+    float a[8], kk[8], c0[8], a2[8], kk2[8], c02[8];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const long long i = i0 + k * kBlock;
+      if (i >= n8) break;
+      if (k == 0 || !fixed) {
+        const int c = (int)(i % c8) << 3;
+        ld8f(coef + c, a); ld8f(coef + C + c, kk); ld8f(coef + 2 * C + c, c0);
+        ld8f(coef2 + c, a2); ld8f(coef2 + C + c, kk2); ld8f(coef2 + 2 * C + c, c02);
+      }
+      float v[8], w[8], g[8];
+      cvt8(xr[k], v); cvt8(zr[k], w); cvt8(gr[k], g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = (mbits[k] >> e) & 1u ? g[e] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = fmaf(a[e], g[e], fmaf(kk[e], v[e], c0[e]));
+        w[e] = fmaf(a2[e], g[e], fmaf(kk2[e], w[e], c02[e]));
+      }
+      st8bf(dx + i * 8, v);
+      st8bf(dz + i * 8, w);
+    }
+  }
+}
+
 static int g_apply_rows = 2;   // items per thread of the apply kernels: 1, 2 or 4
 static int g_apply_nt = 1;     // non-temporal activation loads
 
@@ -640,11 +694,9 @@ DTF_API int dtf_bn_bwd(const void* x, const void* dy, const void* y, const float
 // of the following convolution): col_stats is fp32 [n_rows][2][C] holding sum dy' and sum dy' * (x - mean) over
 // disjoint row sets, dy' being the gradient after the ReLU mask. x and dy are then read once (by the apply pass).
 // workspace: fp32 [kFoldRows * 2 * C].
-DTF_API int dtf_bn_bwd_stats(const void* x, const void* dy, const void* y, const float* gamma, const float* mean,
-                             const float* invstd, const float* scale, const float* shift, void* dx, void* dres,
-                             float* dgamma, float* dbeta, float* coef, const float* col_stats, int n_rows,
-                             float* workspace, long long M, int C, int relu, void* counters, hipStream_t stream) {
-  if (M <= 0 || C <= 0) return 0;
+static int bn_bwd_stats_coef(const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                             float* coef, const float* col_stats, int n_rows, float* workspace, long long M, int C,
+                             void* counters, hipStream_t stream) {
   if (C % 8 || !col_stats || n_rows < 1) return -1;
   const float* part = col_stats;
   int np = n_rows;
@@ -653,8 +705,7 @@ DTF_API int dtf_bn_bwd_stats(const void* x, const void* dy, const void* y, const
     f.gamma = gamma; f.mean = const_cast<float*>(mean); f.invstd = const_cast<float*>(invstd); f.dgamma = dgamma;
     f.dbeta = dbeta; f.cA = coef; f.cK = coef + C; f.c0 = coef + 2 * C; f.M = M; f.C = C;
     launch_reduce_finalize<1>(col_stats, n_rows, workspace, (unsigned*)counters, f, stream);
-    launch_apply_bwd(x, dy, y, coef, scale, shift, dx, dres, M, C, relu, stream);
-    return (int)hipGetLastError();
+    return 0;
   }
   if (n_rows > kFoldAbove) {
     const int per = (n_rows + kFoldRows - 1) / kFoldRows;
@@ -665,7 +716,47 @@ DTF_API int dtf_bn_bwd_stats(const void* x, const void* dy, const void* y, const
   }
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, part, np, gamma,
                      mean, invstd, dgamma, dbeta, coef, coef + C, coef + 2 * C, M, C, 1);
+  return 0;
+}
+
+DTF_API int dtf_bn_bwd_stats(const void* x, const void* dy, const void* y, const float* gamma, const float* mean,
+                             const float* invstd, const float* scale, const float* shift, void* dx, void* dres,
+                             float* dgamma, float* dbeta, float* coef, const float* col_stats, int n_rows,
+                             float* workspace, long long M, int C, int relu, void* counters, hipStream_t stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (bn_bwd_stats_coef(gamma, mean, invstd, dgamma, dbeta, coef, col_stats, n_rows, workspace, M, C, counters, stream))
+    return -1;
   launch_apply_bwd(x, dy, y, coef, scale, shift, dx, dres, M, C, relu, stream);
+  return (int)hipGetLastError();
+}
+
+// The closing norm of a down-sampling block (input x, sums of its gradient already in col_stats as for
+// dtf_bn_bwd_stats) together with the plain norm of the down-sampling branch (input z; `2` arguments), which receives
+// the same gradient dy under the same mask bits: the branch norm's two sums are reduced here (one pass over dy, the
+// bits and z), then ONE apply pass writes dx and dz. workspace2: fp32 [dtf_bn_num_partials * 2 * C].
+DTF_API int dtf_bn_bwd_stats_dual(const void* x, const void* dy, const void* mask, const float* gamma, const float* mean,
+                                  const float* invstd, void* dx, float* dgamma, float* dbeta, float* coef,
+                                  const float* col_stats, int n_rows, float* workspace, const void* z,
+                                  const float* gamma2, const float* mean2, const float* invstd2, void* dz,
+                                  float* dgamma2, float* dbeta2, float* coef2, float* workspace2, long long M, int C,
+                                  void* counters, hipStream_t stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (!mask || !z || !dz || !dx) return -1;
+  if (bn_bwd_stats_coef(gamma, mean, invstd, dgamma, dbeta, coef, col_stats, n_rows, workspace, M, C, counters, stream))
+    return -1;
+  const int nb = bn_partials_for(M, C);
+  hipLaunchKernelGGL((bn_partial_kernel<1, 3>), dim3(nb, (C + 2047) / 2048), dim3(kBlock), 0, stream,
+                     (const unsigned short*)z, (const unsigned short*)dy, (const unsigned short*)mask, mean2, invstd2,
+                     (const float*)nullptr, (const float*)nullptr, workspace2, M, C);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kBlock), 0, stream, workspace2, nb,
+                     gamma2, mean2, invstd2, dgamma2, dbeta2, coef2, coef2 + C, coef2 + 2 * C, M, C, 0);
+#define AB2(R, NT)                                                                                                       \
+  hipLaunchKernelGGL((bn_apply_bwd2_kernel<R, NT>), dim3(grid_stream(M * (C / 8), kBlock * R)), dim3(kBlock), 0, stream, \
+                     (const unsigned short*)x, (const unsigned short*)z, (const unsigned short*)dy,                     \
+                     (const unsigned char*)mask, coef, coef2, (unsigned short*)dx, (unsigned short*)dz, M, C)
+  if (g_apply_nt) { if (g_apply_rows == 1) AB2(1, true); else AB2(2, true); }
+  else { if (g_apply_rows == 1) AB2(1, false); else AB2(2, false); }
+#undef AB2
   return (int)hipGetLastError();
 }
 

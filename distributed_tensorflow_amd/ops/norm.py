@@ -96,11 +96,15 @@ class ForkToken:
     epilogue anyway, applies the mask there. One pass over the widest activations of the network is saved.
     The output of a plain batch norm (no ReLU, no residual: the norm of a down-sampling branch) carries a token too:
     its own backward reads the gradient together with the mask bits (the kernels' ``relu == 3`` form) instead of a
-    masked copy."""
-    __slots__ = ("masked_grad",)
+    masked copy. That norm also leaves its input, weight and statistics here (``owner``): the norm-add-ReLU then runs
+    the plain norm's backward inside its own (one apply pass for both inputs, the gradient and the bits read once)
+    and leaves the results in ``done`` for the plain norm's backward node to return."""
+    __slots__ = ("masked_grad", "owner", "done")
 
     def __init__(self):
         self.masked_grad = None
+        self.owner = None
+        self.done = None
 
 
 _TOKEN_ATTR = "_dtf_fork_token"
@@ -219,6 +223,8 @@ class _BNActFn(torch.autograd.Function):
         _lib.check(rc, "bn_fwd_train")
         ctx.save_for_backward(x, mask, gamma, stats)
         ctx.request = request
+        if out_token is not None and not relu and residual is None:
+            out_token.owner = (x, gamma, stats)
         if request is not None:
             request.x, request.stats, request.mask, request.relu = x, stats, mask, ctx.relu
         if defer:
@@ -239,10 +245,17 @@ class _BNActFn(torch.autograd.Function):
             # unmasked, with the mask bits: it must arrive here as that very tensor, untouched
             handed, version, mask = tok.masked_grad
             tok.masked_grad = None
+            done, tok.done = tok.done, None
             if (dy.data_ptr() != handed.data_ptr() or dy._version != version or dy.shape != handed.shape):
                 raise RuntimeError("batch_norm_act: the output of a plain batch norm fed a norm-add-ReLU residual AND "
                                    "another consumer; the masked gradient hand-over needs the residual to be its only "
                                    "use (ops.conv.set_bn_stats(False) disables the hand-over)")
+            if done is not None:
+                # the norm-add-ReLU already ran this norm's backward together with its own
+                if ctx.request is not None:
+                    r = ctx.request
+                    r.x = r.stats = r.mask = r.partials = r.dy_ref = None
+                return (done[0], done[1], done[2]) + (None,) * 12
             if dy.is_contiguous(memory_format=torch.channels_last) and dy.dtype == torch.bfloat16 and dy.shape == x.shape:
                 relu_code, y = 3, mask
             else:
@@ -264,7 +277,29 @@ class _BNActFn(torch.autograd.Function):
         nb = lib.dtf_bn_num_partials(ctypes.c_longlong(M), C)
         ws = _scratch(dev, nb * 2 * C)
         req = ctx.request
-        if req is not None and req.matches(dy):
+        owner = token.owner if token is not None else None
+        if (_dual_bwd and owner is not None and req is not None and req.matches(dy) and relu_code == 3
+                and owner[0].shape == x.shape and owner[0].dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+                and owner[0].is_contiguous(memory_format=torch.channels_last)):
+            # closing norm of a down-sampling block: the branch norm's backward runs here too (see ForkToken)
+            z, gamma2, stats2 = owner
+            part = req.partials
+            fold = max(nb, 512) * 2 * C
+            ws = _scratch(dev, fold + nb * 2 * C)
+            dz = torch.empty_like(z)
+            dgb2 = torch.empty(2, C, dtype=torch.float32, device=dev)
+            coef2 = torch.empty(3, C, dtype=torch.float32, device=dev)
+            rc = lib.dtf_bn_bwd_stats_dual(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(stats[0]),
+                                           _lib.ptr(stats[1]), _lib.ptr(dx), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]),
+                                           _lib.ptr(coef), _lib.ptr(part), int(part.shape[0]), _lib.ptr(ws),
+                                           _lib.ptr(z), _lib.ptr(gamma2), _lib.ptr(stats2[0]), _lib.ptr(stats2[1]),
+                                           _lib.ptr(dz), _lib.ptr(dgb2[0]), _lib.ptr(dgb2[1]), _lib.ptr(coef2),
+                                           ctypes.c_void_p(ws.data_ptr() + 4 * fold), ctypes.c_longlong(M), C,
+                                           _reduce_counters(dev, C), _lib.stream_ptr(dev))
+            token.done = (dz, dgb2[0], dgb2[1])
+            global dual_launches
+            dual_launches += 1
+        elif req is not None and req.matches(dy):
             # the convolution that consumed the output already reduced this very gradient
             part = req.partials
             ws = _scratch(dev, max(nb, 512) * 2 * C)
@@ -326,6 +361,9 @@ def batch_norm_lazy(x, gamma, beta, running_mean, running_var, momentum: float =
     return DeferredNorm(alias, stats[2], stats[3], False)
 
 
+# DTF_BN_DUAL_BWD=0 runs the backward of a down-sampling branch's norm as a pass of its own (A/B switch)
+_dual_bwd = __import__("os").environ.get("DTF_BN_DUAL_BWD", "1") != "0"
+dual_launches = 0      # how often the one-pass form ran (tests)
 # DTF_BN_LAZY_RESIDUAL=0 writes the down-sampling branch's normalised tensor as before (A/B switch)
 _lazy_residual = __import__("os").environ.get("DTF_BN_LAZY_RESIDUAL", "1") != "0"
 

@@ -1722,3 +1722,45 @@ def test_lazy_down_sampling_norm_matches_the_written_one(block):
     assert rel(a[1], b[1]) < 8e-2
     for n in a[2]:
         assert rel(a[2][n], b[2][n]) < 8e-2, (n, rel(a[2][n], b[2][n]))
+
+
+@pytest.mark.parametrize("lazy", [True, False], ids=["lazy", "written"])
+def test_down_sampling_block_backward_in_one_apply_pass(lazy):
+    """The backward of a down-sampling branch's norm run inside the closing norm-add-ReLU's backward (one apply pass
+    writes both input gradients) against the two separate passes: the same sums in the same order and the same fused
+    multiply-adds per element, so every gradient is bit-identical. The block is followed by a second one, whose first
+    convolution hands the closing norm its reduced gradient sums: only then does the one-pass form apply."""
+    from distributed_tensorflow_amd.models import resnet as R
+    from distributed_tensorflow_amd.ops import norm
+    torch.manual_seed(22)
+    net = torch.nn.Sequential(R.Bottleneck(64, 32, 2), R.Bottleneck(128, 32, 1)).to(DEV)
+    for m in net.modules():
+        if isinstance(m, R.Conv):
+            m.weight.data = m.weight.data.bfloat16().contiguous(memory_format=torch.channels_last)
+        if isinstance(m, R.BNAct):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+    net.train()
+    x = torch.randn(8, 64, 16, 16, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    res, launches = {}, {}
+    try:
+        norm._lazy_residual = lazy
+        for dual in (True, False):
+            norm._dual_bwd = dual
+            before = norm.dual_launches
+            for p in net.parameters():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            out = net(xi)
+            (out.float() * torch.linspace(0.5, 1.5, out.numel(), device=DEV).reshape(out.shape)).sum().backward()
+            res[dual] = (xi.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()})
+            launches[dual] = norm.dual_launches - before
+    finally:
+        norm._lazy_residual = True
+        norm._dual_bwd = True
+    assert launches == {True: 1, False: 0}
+    assert torch.equal(res[True][0], res[False][0])
+    for n in res[True][1]:
+        assert torch.equal(res[True][1][n], res[False][1][n]), n
+    g = res[True][1]["0.down_bn.weight"]
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
