@@ -393,6 +393,8 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd2_kernel(const unsigned sh
 }
 
 static int g_apply_rows = 2;   // items per thread of the apply kernels: 1, 2 or 4
+static int g_apply2_rows = 2;  // ... of the two-norm backward apply kernel: 1 or 2 (measurement hook)
+DTF_API void dtf_set_bn_apply2_rows(int r) { g_apply2_rows = r == 1 ? 1 : 2; }
 static int g_apply_nt = 1;     // non-temporal activation loads
 
 DTF_API int dtf_set_bn_apply_rows(int r, int nt) {
@@ -754,8 +756,8 @@ DTF_API int dtf_bn_bwd_stats_dual(const void* x, const void* dy, const void* mas
   hipLaunchKernelGGL((bn_apply_bwd2_kernel<R, NT>), dim3(grid_stream(M * (C / 8), kBlock * R)), dim3(kBlock), 0, stream, \
                      (const unsigned short*)x, (const unsigned short*)z, (const unsigned short*)dy,                     \
                      (const unsigned char*)mask, coef, coef2, (unsigned short*)dx, (unsigned short*)dz, M, C)
-  if (g_apply_nt) { if (g_apply_rows == 1) AB2(1, true); else AB2(2, true); }
-  else { if (g_apply_rows == 1) AB2(1, false); else AB2(2, false); }
+  if (g_apply_nt) { if (g_apply2_rows == 1) AB2(1, true); else AB2(2, true); }
+  else { if (g_apply2_rows == 1) AB2(1, false); else AB2(2, false); }
 #undef AB2
   return (int)hipGetLastError();
 }
