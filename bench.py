@@ -84,6 +84,14 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # One throwaway child process writes the device's free memory once, before this process touches the GPU: the first
+    # process to work through the HBM of a freshly booted box runs the step 1-1.5 % slower for as long as it lives
+    # (utils/vram.py). Reported in the JSON line; DTF_BENCH_PRETOUCH=0 skips it. Not with several ranks on one GPU.
+    pretouch = None
+    if (a.device == "gpu" and os.environ.get("DTF_BENCH_PRETOUCH", "1") != "0"
+            and os.environ.get("DTF_BENCH_SHARE_GPU") != "1"):
+        from distributed_tensorflow_amd.utils.vram import pretouch as _pretouch
+        pretouch = _pretouch(local_rank)
     if a.device == "gpu":
         if not torch.cuda.is_available():
             print("bench.py needs a GPU (use --device cpu only for plumbing tests)", file=sys.stderr)
@@ -251,6 +259,7 @@ def main() -> int:
             "phase_ms_single_rank_reference": ref_phase, "backward_slowdown": slowdown,
             "comm_host_ms_per_step": hook_ms, "comm_host_ops_per_bucket": ops_per_bucket,
             "replicas_agree": agree,
+            "vram_pretouch": pretouch,
             "final_loss": loss_v,
         }), flush=True)
     comm.shutdown()

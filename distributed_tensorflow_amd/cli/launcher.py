@@ -110,6 +110,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--watchdog-s", type=float, default=0.0, metavar="SECONDS",
                    help="abort a rank (exit code 19) that makes no training progress for this long; 0 = off")
     p.add_argument("--comm-timeout-s", type=float, default=300.0, help="timeout of every collective / rendezvous")
+    p.add_argument("--vram-pretouch", type=str2bool, default=False,
+                   help="before a rank initialises its GPU, a throwaway child process writes the device's free memory "
+                        "once (utils/vram.py: the first process to work through the HBM of a freshly booted machine "
+                        "runs 1-1.5 %% slower for as long as it lives); one rank per GPU only, a few seconds per launch")
     return p
 
 
@@ -178,6 +182,9 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
         if args.cpu_affinity:
             pin_to_core(rank)
         dev = _device_for(rank, args.device)
+        if dev.type == "cuda" and getattr(args, "vram_pretouch", False) and world <= _gpu_count():
+            from ..utils.vram import pretouch
+            pretouch(dev.index or 0)
         if dev.type == "cuda":
             torch.cuda.set_device(dev)
         from ..comm.watchdog import Watchdog, configure_async_errors

@@ -372,7 +372,9 @@ def test_async_ps_applies_every_gradient_and_replicas_end_equal(placement, world
     servers = res if placement == "colocated" else res[:1]
     for _, _, version, _, max_stale in servers:
         assert version == n_workers * steps                      # one apply per (worker, step)
-        assert max_stale <= n_workers * 2
+        # between a worker's pull and the apply of the gradient it then computes, every OTHER worker can at most get
+        # all of its pushes in (a rank the scheduler starves on a busy machine): the bound that holds by construction
+        assert max_stale <= (n_workers - 1) * steps
 
 
 # ------------------------------------------------------------------ replica-consistency debug mode

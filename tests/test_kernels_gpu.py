@@ -1764,3 +1764,15 @@ def test_down_sampling_block_backward_in_one_apply_pass(lazy):
         assert torch.equal(res[True][1][n], res[False][1][n]), n
     g = res[True][1]["0.down_bn.weight"]
     assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+
+
+def test_vram_pretouch_child_process_touches_free_memory():
+    """utils.vram.pretouch: a child process allocates and writes a fraction of the device's free memory and reports
+    how much; this process's own allocations are untouched and usable afterwards."""
+    from distributed_tensorflow_amd.utils.vram import pretouch
+    keep = torch.arange(1024, device=DEV)
+    free, _ = torch.cuda.mem_get_info(DEV)
+    r = pretouch(0, fraction=0.25)
+    assert r["ok"], r
+    assert 0.1 * free / 2 ** 30 <= r["gib"] <= 0.26 * free / 2 ** 30 + 1.0
+    assert int(keep.sum()) == 1023 * 1024 // 2

@@ -318,3 +318,10 @@ def test_load_weights_survives_the_first_asynchronous_apply(tmp_path):
     w, w2 = np.load(tmp_path / "w.npz"), np.load(tmp_path / "w2.npz")
     for k in (k for k in w.files if k.startswith("weight_")):
         assert np.array_equal(w[k], w2[k]), k
+
+
+def test_vram_pretouch_without_a_gpu_reports_failure_and_does_not_raise():
+    """The throwaway first-touch process is best effort: on a machine without a GPU it reports nothing touched."""
+    from distributed_tensorflow_amd.utils.vram import pretouch
+    r = pretouch(0, timeout_s=120.0)
+    assert r["ok"] is False and r["gib"] == 0.0 and r["seconds"] >= 0.0
