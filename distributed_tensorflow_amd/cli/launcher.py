@@ -193,8 +193,18 @@ def _collective_rank(rank: int, world: int, args, model_fn, dataset_fn, kind: st
         # ``port``: a port number (ranks started by hand, one command each), or the launcher's shared cell -- rank 0
         # then binds an ephemeral rendezvous port and publishes it there
         by_hand = isinstance(port, int)
+        # More ranks than GPUs on this machine (the reference's habit of running every role as a local process,
+        # reference initializer.py:134-145,164-173, on a box with fewer cards than roles): RCCL refuses two ranks of
+        # one communicator on one device, so the ranks share the cards and gloo carries the collectives through
+        # host memory. Correct, not fast; ranks started by hand on several machines are taken at their word.
+        backend = None
+        if dev.type == "cuda" and not by_hand and world > _gpu_count() and not os.environ.get("DTF_COMM"):
+            backend = "gloo"
+            if rank == 0:
+                print(f"{world} ranks on {_gpu_count()} GPU(s): ranks share devices, collectives go through host "
+                      "memory (gloo) instead of RCCL", file=sys.stderr)
         comm = Comm.init(rank, world, dev, getattr(args, "master_addr", None) or "127.0.0.1", port if by_hand else 0,
-                         timeout_s=float(getattr(args, "comm_timeout_s", 300.0) or 300.0),
+                         timeout_s=float(getattr(args, "comm_timeout_s", 300.0) or 300.0), backend=backend,
                          port_cell=None if by_hand else port)
         metrics = MetricsLogger(args.metrics, rank=rank)
         sup = SupervisorSink(getattr(args, "supervisor_address", None))

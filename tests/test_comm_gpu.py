@@ -380,3 +380,23 @@ def test_async_ps_loses_no_update_with_several_service_threads_per_owner_on_the_
         assert got[r]["transport"] == transport
         assert got[r]["applies"] == world * steps
         assert got[r]["equal"], got[r]
+
+
+# ----------------------------------------------------------------------------- more ranks than GPUs
+@pytest.mark.parametrize("flags", [["-m", "d", "-ds", "keras"], ["-m", "c", "-cs", "sync"]], ids=["keras", "sync"])
+def test_launcher_with_more_ranks_than_gpus_shares_devices_over_gloo(flags):
+    """The reference runs every role as a local process (reference initializer.py:134-145,164-173); with more
+    ranks than cards RCCL refuses the communicator ("Duplicate GPU detected"), so the launcher lets the ranks share
+    the devices and moves the collectives through host memory. The job must finish with exit code 0."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    if n > 9:
+        pytest.skip("a node with more than 8 GPUs: the case needs more processes than the box allows")
+    env = dict(os.environ, DTF_SYNTH_MNIST_TRAIN="2000", DTF_SYNTH_MNIST_TEST="500")
+    env.pop("DTF_COMM", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "mnist_cnn.py"), *flags, "-n", str(n), "-b", "50",
+                        "--max-steps", "6", "--comm-timeout-s", "120"], env=env, capture_output=True, text=True,
+                       timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ranks share devices" in r.stderr
