@@ -89,7 +89,8 @@ def main() -> int:
     # (utils/vram.py). Reported in the JSON line; DTF_BENCH_PRETOUCH=0 skips it. Not with several ranks on one GPU.
     pretouch = None
     if (a.device == "gpu" and os.environ.get("DTF_BENCH_PRETOUCH", "1") != "0"
-            and os.environ.get("DTF_BENCH_SHARE_GPU") != "1"):
+            and os.environ.get("DTF_BENCH_SHARE_GPU") != "1"
+            and "rocprof" not in os.environ.get("LD_PRELOAD", "")):      # (not under a profiler's preloaded library)
         from distributed_tensorflow_amd.utils.vram import pretouch as _pretouch
         pretouch = _pretouch(local_rank)
     if a.device == "gpu":

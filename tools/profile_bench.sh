@@ -4,6 +4,8 @@
 set -e
 tag=${1:-run}; shift || true
 cd /tmp && export TMPDIR=/tmp
+# no first-touch child process under the profiler (its preloaded library would ride along into the child)
+export DTF_BENCH_PRETOUCH=0
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 3 "$@" > $out/bench.log 2>&1
